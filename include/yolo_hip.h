@@ -1,0 +1,196 @@
+/* yolo_hip.h — C-ABI of libyolo_hip.so, the MI355X (gfx950) replacement for the
+ * conv-backbone + region-layer hot path of zhen8838/K210_Yolo_framework.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) region_layer_*  — byte-for-byte drop-in for the reference's only native
+ *      operator, yolo3_frame_test_public/region_layer.h:7-48.  Same four
+ *      symbols, same struct layouts, same call order and error codes, so a
+ *      main.c-style caller (main.c:278-324) links against this library
+ *      unchanged.  The arithmetic runs on the GPU; rl->output / boxes / probs
+ *      are mirrored back to the host buffers the reference exposes.
+ *
+ *  (2) yk_*            — the batched engine.  The reference has no batched
+ *      native API, so these mirror the call shape its edge path already uses
+ *      for the model run (kendryte SDK, un-vendored):
+ *        kpu_load_kmodel(&task, blob)                 main.c:274  -> yk_plan_create
+ *        kpu_run_kmodel(&task, img, dma, done_cb, 0)  main.c:303  -> yk_run_u8 / yk_run_f32 (async on a stream)
+ *        kpu_get_output(&task, i, &ptr, &bytes)       main.c:310  -> yk_get_output
+ *      and, for the Python path, the decode + per-class NMS block of
+ *      keras_inference.py:94-135 (tf_xywh_to_all tools/utils.py:524-547,
+ *      correct_box keras_inference.py:32-72)            -> yk_decode_py
+ *      plus a batched form of region_layer_run           -> yk_region_batched
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success and a negative code on failure (region_layer_init keeps the
+ * reference's -1..-4); pointers named d_* are DEVICE pointers, h_* host.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * No entry point falls back to a CPU implementation: without a usable HIP
+ * device they fail with YK_ERR_NO_DEVICE.
+ */
+#ifndef YOLO_HIP_H_
+#define YOLO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* (1) drop-in region layer — layouts from region_layer.h:7-42                */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t obj_number;
+    struct {
+        uint32_t x1;
+        uint32_t y1;
+        uint32_t x2;
+        uint32_t y2;
+        uint32_t class_id;
+        float prob;
+    } obj[10];
+} obj_info_t;
+
+typedef struct {
+    float threshold;          /* caller sets before init (main.c:280) */
+    float nms_value;          /* caller sets before init (main.c:281) */
+    uint32_t coords;
+    uint32_t anchor_number;   /* caller sets before init (main.c:278) */
+    float *anchor;            /* borrowed, 2*anchor_number floats (w,h) */
+    uint32_t image_width;
+    uint32_t image_height;
+    uint32_t classes;
+    uint32_t net_width;
+    uint32_t net_height;
+    uint32_t layer_width;
+    uint32_t layer_height;
+    uint32_t boxes_number;
+    uint32_t output_number;
+    void *boxes;              /* boxes_number x {x,y,w,h} float, callee-owned */
+    float *input;             /* borrowed CHW fp32 [A*(5+C), H, W], set before run (main.c:313) */
+    float *output;            /* callee-owned, output_number floats */
+    float *probs_buf;         /* callee-owned, boxes_number*(classes+1) floats */
+    float **probs;            /* callee-owned row pointers into probs_buf */
+} region_layer_t;
+
+typedef void (*callback_draw_box)(uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2,
+                                  uint32_t class_id, float prob);
+
+/* region_layer.h:44-45 / region_layer.c:19-66.  0 ok; -1..-4 = which host buffer
+ * failed to allocate (as the reference); -5 = device state could not be created. */
+int region_layer_init(region_layer_t *rl, int width, int height, int channels, int origin_width,
+                      int origin_height);
+/* region_layer.h:46 / region_layer.c:68-73 */
+void region_layer_deinit(region_layer_t *rl);
+/* region_layer.h:47 / region_layer.c:378-383.  obj_info may be NULL (main.c:314);
+ * like the reference (call commented out at region_layer.c:382) it is not written. */
+void region_layer_run(region_layer_t *rl, obj_info_t *obj_info);
+/* region_layer.h:48 / region_layer.c:385-404.  Negative float -> uint32 is UB in the
+ * reference; here it is defined as (uint32_t)(int64_t)x, the x86-64 behaviour. */
+void region_layer_draw_boxes(region_layer_t *rl, callback_draw_box callback);
+
+/* ------------------------------------------------------------------------- */
+/* (2) batched engine                                                         */
+/* ------------------------------------------------------------------------- */
+#define YK_OK 0
+#define YK_ERR_ARG (-10)
+#define YK_ERR_HIP (-11)
+#define YK_ERR_UNSUPPORTED (-12)
+#define YK_ERR_NO_DEVICE (-13)
+#define YK_ERR_NOMEM (-14)
+
+/* op codes / activation codes / field indices of one op row (int32 x YK_OP_FIELDS);
+ * produced by k210_yolo_framework_amd/netspec.py:compile_plan */
+enum { YK_OP_CONV = 1, YK_OP_DWCONV = 2, YK_OP_MAXPOOL = 3, YK_OP_UPSAMPLE = 4, YK_OP_CONCAT = 5, YK_OP_ADD = 6 };
+enum { YK_ACT_NONE = 0, YK_ACT_RELU = 1, YK_ACT_RELU6 = 2, YK_ACT_LEAKY = 3 };
+enum {
+    YK_F_TYPE = 0, YK_F_IN0, YK_F_IN1, YK_F_OUT, YK_F_CIN, YK_F_COUT, YK_F_K, YK_F_STRIDE, YK_F_PAD_T,
+    YK_F_PAD_L, YK_F_ACT, YK_F_ALPHA /* float bits */, YK_F_W_OFF, YK_F_SCALE_OFF, YK_F_BIAS_OFF, YK_F_FLAGS,
+    YK_F_IN_H, YK_F_IN_W, YK_F_OUT_H, YK_F_OUT_W
+};
+#define YK_OP_FIELDS 24
+#define YK_FLAG_NET_OUTPUT 1
+#define YK_MAX_LAYERS 4
+#define YK_MAX_ANCHORS 8
+
+typedef struct yk_plan yk_plan_t; /* opaque */
+
+/* Last error text of the calling thread ("" if none). */
+const char *yk_last_error(void);
+/* Number of visible HIP devices (0 when there is none / no driver). */
+int yk_device_count(void);
+
+/* kpu_load_kmodel analogue.  ops: [n_ops][YK_OP_FIELDS] int32; tensors: [n_tensors][4]
+ * int32 (h, w, c, is_input); blob: fp32 weights/scale/bias addressed by the op rows.
+ * The plan owns every device buffer (weights in fp16, activation arena sized for
+ * max_batch).  Arithmetic: fp16 storage, fp32 accumulation, fp32 network outputs. */
+int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
+                   const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
+                   int device);
+void yk_plan_destroy(yk_plan_t *p);
+
+/* kpu_run_kmodel analogue, asynchronous on `stream`.
+ * yk_run_u8: d_frames = device uint8 [batch][H][W][3]; fuses Helper._process_img's
+ *            `img / np.max(img)` (tools/utils.py:405) as a per-image max reduction.
+ * yk_run_f32: d_input = device float [batch][H][W][3], already normalised (what
+ *            yolo_model.predict receives, keras_inference.py:88). */
+int yk_run_u8(yk_plan_t *p, const uint8_t *d_frames, int batch, void *stream);
+int yk_run_f32(yk_plan_t *p, const float *d_input, int batch, void *stream);
+
+/* kpu_get_output analogue: borrowed device pointer to network output idx,
+ * NHWC fp32 [max_batch][h][w][A*(5+C)] (rows beyond the last run's batch are stale). */
+int yk_get_output(yk_plan_t *p, int idx, float **d_ptr, size_t *bytes, int *h, int *w, int *c);
+
+/* Debug/parity access to any intermediate activation (fp16, channel pitch padded
+ * to a multiple of 8): copies tensor `tid` of the last run to host as fp32 NHWC. */
+int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_dst, size_t dst_elems);
+/* Number of kernel launches one yk_run_* issues (after fusion). */
+int yk_plan_launch_count(const yk_plan_t *p);
+/* Name/shape of the i-th launch for bench/roofline bookkeeping. */
+int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, double *flops_per_image,
+                        double *bytes_per_image);
+
+/* ---- decode ---------------------------------------------------------------- */
+typedef struct {
+    int32_t n_layers;                       /* output scales (2 or 3) */
+    int32_t anchor_num;                     /* A */
+    int32_t class_num;                      /* C */
+    int32_t in_h, in_w;                     /* network input size (224, 320) */
+    int32_t out_h[YK_MAX_LAYERS];           /* Helper.out_hw */
+    int32_t out_w[YK_MAX_LAYERS];
+    float anchors[YK_MAX_LAYERS][YK_MAX_ANCHORS][2]; /* Helper.anchors (w,h), image-relative */
+} yk_decode_cfg_t;
+
+/* Python-mode decode + per-class NMS for a batch (keras_inference.py:94-135).
+ * d_pred[l]: device fp32 [batch][out_h][out_w][A][5+C] (== the engine's outputs).
+ * d_image_hw: device float [batch][2] original image (h,w) per image, or NULL = in_hw.
+ * d_dets:   device float [batch][C*max_out][6] rows (top,left,bottom,right,score,class),
+ *           class-major ascending, score-descending within a class (the reference's order).
+ * d_counts: device int32 [batch].
+ * Semantics restated from tensorflow 1.14 tf.image.non_max_suppression: score >= obj_thresh
+ * kept, greedy, suppress iff IoU > iou_thresh, at most max_out (30) per class; equal scores
+ * are ordered by ascending box index (TF leaves it unspecified). */
+int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                 float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, void *stream);
+
+/* C-mode (region_layer.c:121-283) for a batch of layer outputs without host round trips.
+ * d_input element (b, anchor n, entry e, row y, col x) is at
+ *   b*stride_b + n*stride_n + e*stride_e + y*stride_y + x*stride_x   (floats)
+ * so both the K210 CHW layout and the engine's NHWC outputs can be consumed.
+ * d_boxes: [batch][A*H*W][4] (x,y,w,h), d_probs: [batch][A*H*W][C+1]; box index = n*H*W + y*W + x. */
+typedef struct {
+    int32_t layer_w, layer_h, anchor_num, classes;
+    int32_t net_w, net_h, image_w, image_h;
+    float threshold, nms_value;
+    float anchor[2 * YK_MAX_ANCHORS];
+    int64_t stride_b, stride_n, stride_e, stride_y, stride_x;
+} yk_region_cfg_t;
+int yk_region_batched(const yk_region_cfg_t *cfg, const float *d_input, int batch, float *d_output /* may be NULL */,
+                      float *d_boxes, float *d_probs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H_ */
