@@ -1,0 +1,89 @@
+// yk_conv.h — launch wrappers of the gfx950 conv-stack kernels (yk_conv.hip).
+//
+// Storage rule (mirrored by oracle/yolo_net_ref.c emulate_f16): activations are fp16 NHWC with the
+// channel pitch padded to a multiple of 8 (pad lanes hold zeros); weights fp16, reduction axis
+// contiguous and zero-padded the same way; accumulation, BatchNorm scale/bias and activation in
+// fp32; network outputs fp32 with exact pitch.
+#pragma once
+#include "yk_common.h"
+
+typedef _Float16 yk_half;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+static inline int yk_pad8(int c) { return (c + 7) & ~7; }
+
+// ---- implicit-GEMM conv (1x1 / 3x3, stride 1/2, optional [up2(src0), src1] concat input) -------
+struct igemm_args {
+    const yk_half *in0, *in1;   // in1 may be null
+    int c0p, c1p;               // channel pitch of the sources (c1p = 0 without concat)
+    int up0;                    // src0 is read through a nearest 2x upsample
+    int Hi, Wi;                 // logical input size (after upsample / concat)
+    int Ho, Wo;
+    int ks, stride, pad_t, pad_l;
+    int M, N, K;                // M = B*Ho*Wo, N = Cout, K = ks*ks*(c0p+c1p)
+    const yk_half *w;           // [N][K]
+    const float *scale, *bias;  // [N]
+    int act;
+    float alpha;
+    const yk_half *res;         // residual added after the activation (pitch resp), or null
+    int resp;
+    void *out;                  // fp16 pitch outp, or fp32 pitch outp when out_f32
+    int outp;
+    // optional fused depthwise producer (dw3x3 + BN + act feeding the 1x1 GEMM as its A operand)
+    const yk_half *dw_w;        // [9][c0p] fp16 or null
+    const float *dw_scale, *dw_bias;
+    int dw_act, dw_stride, dw_pad_t, dw_pad_l, dw_Hi, dw_Wi;
+};
+enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_128x80,
+       IGEMM_F32_128x64, IGEMM_NUM };
+int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st);
+int yk_igemm_pick(const igemm_args &a, bool out_f32);
+const char *yk_igemm_name(int cfg);
+
+// fused DepthwiseConv2D(3x3)+BN+act -> Conv2D(1x1)+BN+act: the depthwise tile is produced straight
+// into LDS (never written to HBM) and consumed as the MFMA pixel operand; weights stream from L2.
+enum { FUSED_128x48 = 0, FUSED_128x96, FUSED_64x192, FUSED_32x192, FUSED_NUM };
+bool yk_igemm_fused_ok(int c0p, int cout);
+int yk_igemm_fused_pick(const igemm_args &a);
+const char *yk_igemm_fused_name(int cfg);
+int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st);
+
+// ---- first conv: 3 input channels, u8 (with fused img/max(img)) or fp32 input -------------------
+struct first_args {
+    const void *in;             // u8 or f32 [B][Hi][Wi][3]
+    const unsigned *img_max;    // [B] per-image max (u8 path) or null
+    int in_f32;
+    int B, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, Cout, outp;
+    const float *w;             // [27][Cout] fp32 holding fp16-rounded values, tap-major
+    const float *scale, *bias;
+    int act;
+    float alpha;
+    yk_half *out;
+};
+int yk_launch_first(const first_args &a, hipStream_t st);
+int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st);
+
+// ---- depthwise 3x3 ------------------------------------------------------------------------------
+struct dw_args {
+    const yk_half *in;
+    int B, Hi, Wi, Ho, Wo, Cp, stride, pad_t, pad_l;
+    const yk_half *w;           // [9][Cp]
+    const float *scale, *bias;  // [Cp] (pad lanes: scale 0, bias 0)
+    int act;
+    float alpha;
+    yk_half *out;
+};
+int yk_launch_dw(const dw_args &a, hipStream_t st);
+
+// ---- 2x2 max pool ('same') ----------------------------------------------------------------------
+struct pool_args {
+    const yk_half *in;
+    int B, Hi, Wi, Ho, Wo, Cp, stride;
+    yk_half *out;
+};
+int yk_launch_pool(const pool_args &a, hipStream_t st);
+
+// ---- residual add fallback (only when it cannot be fused into a conv epilogue) ------------------
+int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, hipStream_t st);

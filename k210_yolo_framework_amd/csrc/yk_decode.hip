@@ -1,0 +1,237 @@
+// yk_decode.hip — Python-mode decode + per-class NMS on gfx950 (batched).
+//
+// Replaces, for a whole batch and without host round trips,
+//   keras_inference.py:94-111   sigmoid(cls)*sigmoid(conf), reshape(-1,..) in (layer,h,w,anchor) order
+//   tools/utils.py:545-546      tf_xywh_to_all
+//   keras_inference.py:51-72    correct_box
+//   keras_inference.py:113-135  scores >= obj_thresh ; per class tf.image.non_max_suppression(…, 30, iou)
+// which the reference runs as ~100 eager TF op dispatches per image.
+//
+// Three launches: decode (thread per box, coalesced class-major score planes) -> NMS (one
+// wavefront per (image, class), yk_nms.h) -> compaction to the reference's class-major row order.
+// Compiled with -ffp-contract=off: one rounding per TF op, like the eager fp32 graph.
+#include "yk_common.h"
+#include "yk_nms.h"
+
+struct decode_args {
+    int L, A, C, E;
+    int in_h, in_w;
+    int out_h[YK_MAX_LAYERS], out_w[YK_MAX_LAYERS];
+    int off[YK_MAX_LAYERS + 1];   // first global box index of each layer
+    float anchors[YK_MAX_LAYERS][YK_MAX_ANCHORS][2];
+    const float *pred[YK_MAX_LAYERS];
+};
+
+__device__ __forceinline__ float tf_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ void __launch_bounds__(256) decode_py_kernel(decode_args a, int batch, const float *__restrict__ image_hw,
+                                                        float4 *__restrict__ boxes, float *__restrict__ scores_t) {
+    const int ntot = a.off[a.L];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * ntot) return;
+    const int b = t / ntot, g = t - b * ntot;
+    int l = 0;
+    while (l + 1 < a.L && g >= a.off[l + 1]) ++l;
+    const int r = g - a.off[l];
+    const int cell = r / a.A, an = r - cell * a.A;
+    const int h = a.out_h[l], w = a.out_w[l];
+    const int row = cell / w, col = cell - row * w;
+    const float *p = a.pred[l] + ((size_t)(b * h + row) * w + col) * a.A * a.E + (size_t)an * a.E;
+
+    const float conf = tf_sigmoid(p[4]);
+    for (int c = 0; c < a.C; ++c) scores_t[((size_t)b * a.C + c) * ntot + g] = tf_sigmoid(p[5 + c]) * conf;
+
+    // tf_xywh_to_all (tools/utils.py:545-546)
+    const float x = (tf_sigmoid(p[0]) + (float)col) / (float)w;
+    const float y = (tf_sigmoid(p[1]) + (float)row) / (float)h;
+    const float bw = expf(p[2]) * a.anchors[l][an][0];
+    const float bh = expf(p[3]) * a.anchors[l][an][1];
+
+    // correct_box (keras_inference.py:51-72), (y,x) order
+    const float in_h = (float)a.in_h, in_w = (float)a.in_w;
+    const float im_h = image_hw ? image_hw[2 * b] : in_h, im_w = image_hw ? image_hw[2 * b + 1] : in_w;
+    const float rh = in_h / im_h, rw = in_w / im_w;
+    const float m = rh < rw ? rh : rw;
+    const float new_h = rintf(im_h * m), new_w = rintf(im_w * m);       // tf.round = half-to-even
+    const float off_y = (in_h - new_h) / 2.f / in_h, off_x = (in_w - new_w) / 2.f / in_w;
+    const float sc_y = in_h / new_h, sc_x = in_w / new_w;
+    const float cy = (y - off_y) * sc_y, cx = (x - off_x) * sc_x;
+    const float hh = bh * sc_y, ww = bw * sc_x;
+    const float hy = hh / 2.f, hx = ww / 2.f;
+    boxes[(size_t)b * ntot + g] = make_float4((cy - hy) * im_h, (cx - hx) * im_w, (cy + hy) * im_h, (cx + hx) * im_w);
+}
+
+// TF 1.14 non_max_suppression_op.cc IOU on (y1,x1,y2,x2)
+__device__ __forceinline__ float tf_iou(const float4 &i, const float4 &j) {
+    const float ymin_i = fminf(i.x, i.z), xmin_i = fminf(i.y, i.w), ymax_i = fmaxf(i.x, i.z), xmax_i = fmaxf(i.y, i.w);
+    const float ymin_j = fminf(j.x, j.z), xmin_j = fminf(j.y, j.w), ymax_j = fmaxf(j.x, j.z), xmax_j = fmaxf(j.y, j.w);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.f || area_j <= 0.f) return 0.f;
+    const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+    const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+    const float inter = fmaxf(iy1 - iy0, 0.f) * fmaxf(ix1 - ix0, 0.f);
+    return inter / (area_i + area_j - inter);
+}
+
+// grid (C, batch), one wavefront.  sel_g/sel_s: [batch][C][max_out]; cnt: [batch][C]
+__global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_thresh, float iou_thresh, int max_out,
+                                                    const float4 *__restrict__ boxes, float *__restrict__ scores_t,
+                                                    int *__restrict__ sel_g, float *__restrict__ sel_s,
+                                                    int *__restrict__ cnt) {
+    __shared__ yk_cand_lds L;
+    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float *sc = scores_t + ((size_t)b * C + c) * ntot;
+    const float4 *bx = boxes + (size_t)b * ntot;
+    int *og = sel_g + ((size_t)b * C + c) * max_out;
+    float *os = sel_s + ((size_t)b * C + c) * max_out;
+    int n = 0;
+    for (int base = 0; base < ntot; base += 64) {
+        int i = base + lane;
+        float s = (i < ntot) ? sc[i] : -INFINITY;
+        bool f = (i < ntot) && (s >= obj_thresh);                    // keras_inference.py:116 (>=)
+        unsigned long long m = __ballot(f);
+        int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (f && pos < YK_NMS_MAXC) {
+            L.s[pos] = s;
+            L.idx[pos] = i;
+            L.box[pos] = bx[i];
+        }
+        n += __popcll(m);
+    }
+    __syncthreads();
+    int kept = 0;
+    if (n <= YK_NMS_MAXC) {
+        kept = yk_wave_greedy_nms(
+            n, L.s, L.idx, L.box, iou_thresh, max_out, [](const float4 &a, const float4 &d) { return tf_iou(d, a); },
+            [&](int rank, int pos) {
+                if (lane == 0) {
+                    og[rank] = L.idx[pos];
+                    os[rank] = L.s[pos];
+                }
+            },
+            [](int) {});
+    } else {
+        // overflow path: in place on the (scratch) score plane; dead = -INF
+        while (kept < max_out) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff, bpos = -1;
+            for (int i = lane; i < ntot; i += 64) {
+                float v = sc[i];
+                if (v >= obj_thresh && v > -INFINITY && (bpos < 0 || v > best)) {
+                    best = v;
+                    bidx = i;
+                    bpos = i;
+                }
+            }
+            yk_wave_argmax(best, bidx, bpos);
+            if (bpos < 0) break;
+            const float4 wb = bx[bpos];
+            __syncthreads();
+            if (lane == 0) {
+                og[kept] = bpos;
+                os[kept] = best;
+                sc[bpos] = -INFINITY;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int i = lane; i < ntot; i += 64) {
+                float v = sc[i];
+                if (v >= obj_thresh && v > -INFINITY && tf_iou(bx[i], wb) > iou_thresh) sc[i] = -INFINITY;
+            }
+            __threadfence_block();
+            __syncthreads();
+            ++kept;
+        }
+    }
+    if (lane == 0) cnt[b * C + c] = kept;
+}
+
+// grid (batch), 64 threads: class-major concatenation (keras_inference.py:133-135)
+__global__ void __launch_bounds__(64) compact_py_kernel(int ntot, int C, int max_out, const float4 *__restrict__ boxes,
+                                                        const int *__restrict__ sel_g, const float *__restrict__ sel_s,
+                                                        const int *__restrict__ cnt, float *__restrict__ dets,
+                                                        int *__restrict__ counts) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int base = 0;
+    for (int c = 0; c < C; ++c) {
+        const int k = cnt[b * C + c];
+        for (int j = lane; j < k; j += 64) {
+            const int g = sel_g[((size_t)b * C + c) * max_out + j];
+            const float4 bb = boxes[(size_t)b * ntot + g];
+            float *d = dets + ((size_t)b * C * max_out + base + j) * 6;
+            d[0] = bb.x;
+            d[1] = bb.y;
+            d[2] = bb.z;
+            d[3] = bb.w;
+            d[4] = sel_s[((size_t)b * C + c) * max_out + j];
+            d[5] = (float)c;
+        }
+        base += k;
+    }
+    if (lane == 0) counts[b] = base;
+}
+
+extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                            float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts,
+                            void *stream) {
+    if (!cfg || !d_pred || !d_dets || !d_counts || batch <= 0 || max_out <= 0 || cfg->n_layers <= 0 ||
+        cfg->n_layers > YK_MAX_LAYERS || cfg->anchor_num <= 0 || cfg->anchor_num > YK_MAX_ANCHORS ||
+        cfg->class_num <= 0) {
+        yk_set_error("yk_decode_py: bad argument");
+        return YK_ERR_ARG;
+    }
+    decode_args a;
+    memset(&a, 0, sizeof(a));
+    a.L = cfg->n_layers;
+    a.A = cfg->anchor_num;
+    a.C = cfg->class_num;
+    a.E = 5 + cfg->class_num;
+    a.in_h = cfg->in_h;
+    a.in_w = cfg->in_w;
+    int off = 0;
+    for (int l = 0; l < a.L; ++l) {
+        if (!d_pred[l] || cfg->out_h[l] <= 0 || cfg->out_w[l] <= 0) {
+            yk_set_error("yk_decode_py: layer %d null / empty", l);
+            return YK_ERR_ARG;
+        }
+        a.out_h[l] = cfg->out_h[l];
+        a.out_w[l] = cfg->out_w[l];
+        a.off[l] = off;
+        off += cfg->out_h[l] * cfg->out_w[l] * a.A;
+        a.pred[l] = d_pred[l];
+        for (int n = 0; n < a.A; ++n) {
+            a.anchors[l][n][0] = cfg->anchors[l][n][0];
+            a.anchors[l][n][1] = cfg->anchors[l][n][1];
+        }
+    }
+    a.off[a.L] = off;
+    const int ntot = off;
+    int dev = yk_current_device();
+    if (dev < 0) {
+        yk_set_error("yk_decode_py: no HIP device");
+        return YK_ERR_NO_DEVICE;
+    }
+    const size_t box_b = (size_t)batch * ntot * sizeof(float4);
+    const size_t sc_b = (size_t)batch * a.C * ntot * sizeof(float);
+    const size_t sel_b = (size_t)batch * a.C * max_out * sizeof(int);
+    const size_t cnt_b = (size_t)batch * a.C * sizeof(int);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char *ws = (char *)yk_scratch(dev, stream, 0, up(box_b) + up(sc_b) + 2 * up(sel_b) + up(cnt_b));
+    if (!ws) return YK_ERR_NOMEM;
+    float4 *boxes = (float4 *)ws;
+    float *scores_t = (float *)(ws + up(box_b));
+    int *sel_g = (int *)(ws + up(box_b) + up(sc_b));
+    float *sel_s = (float *)(ws + up(box_b) + up(sc_b) + up(sel_b));
+    int *cnt = (int *)(ws + up(box_b) + up(sc_b) + 2 * up(sel_b));
+    hipStream_t st = (hipStream_t)stream;
+    const int total = batch * ntot;
+    hipLaunchKernelGGL(decode_py_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a, batch, d_image_hw, boxes,
+                       scores_t);
+    hipLaunchKernelGGL(nms_py_kernel, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out,
+                       boxes, scores_t, sel_g, sel_s, cnt);
+    hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(64), 0, st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
+                       d_dets, d_counts);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}

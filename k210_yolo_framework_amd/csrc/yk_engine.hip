@@ -1,0 +1,560 @@
+// yk_engine.hip — plan compiler + executor behind yk_plan_create / yk_run_* / yk_get_output.
+//
+// A plan (k210_yolo_framework_amd/netspec.py) is compiled ONCE into a flat launch list:
+//   * UpSampling2D / Concatenate never materialise: they become addressing modes of the consuming
+//     conv's A-operand loader (yolonet.py:31-38 head pattern, Darknet FPN :167-172);
+//   * Add (MobileNet-v2 / Darknet residual) is folded into the producing conv's epilogue;
+//   * DepthwiseConv2D+BN+ReLU followed by its 1x1 Conv2D+BN+LeakyReLU is fused into one launch
+//     where profitable (the depthwise tile lives only in LDS) — see YK_FUSE_DWPW;
+//   * every weight tensor is converted to fp16 with its reduction axis padded to the activation
+//     channel pitch, BatchNorm stays an fp32 (scale, bias) epilogue.
+// Running a plan replays the launch list on the caller's stream; nothing is allocated at run time.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "yk_conv.h"
+
+namespace {
+
+uint16_t f2h_bits(float f) {   // round-to-nearest-even fp32 -> fp16 bits
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0));
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (ax < 0x38800000u) {   // subnormal half
+        if (ax < 0x33000000u) return (uint16_t)sign;   // < 2^-25 -> 0 (ties-to-even at exactly 2^-25 -> 0)
+        const int e = (int)(ax >> 23);
+        uint32_t man = (ax & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                     // 14..24
+        const uint32_t lsb = 1u << shift, half = lsb >> 1;
+        uint32_t r = man >> shift;
+        const uint32_t rem = man & (lsb - 1);
+        if (rem > half || (rem == half && (r & 1))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    const uint32_t lsb = (ax >> 13) & 1u;
+    ax += 0xfffu + lsb;
+    return (uint16_t)(sign | ((ax - 0x38000000u) >> 13));
+}
+float h2f_bits(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) {
+                m <<= 1;
+                ++sh;
+            }
+            x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD };
+enum { T_REAL = 0, T_UP = 1, T_CAT = 2 };
+
+struct tinfo {
+    int h = 0, w = 0, c = 0, cp = 0;
+    int kind = T_REAL, src0 = -1, src1 = -1;
+    bool net_out = false, is_input = false;
+    yk_half *d = nullptr;
+    float *d32 = nullptr;
+    int uses = 0;
+};
+
+struct launch {
+    int kind = 0, cfg = 0;
+    igemm_args g;
+    first_args f;
+    dw_args d;
+    pool_args p;
+    const yk_half *add_a = nullptr, *add_b = nullptr;
+    yk_half *add_o = nullptr;
+    size_t add_n8_per_image = 0;
+    int Ho = 0, Wo = 0;
+    std::string name;
+    double flops = 0, bytes = 0;
+};
+
+}   // namespace
+
+struct yk_plan {
+    int device = 0, max_batch = 0;
+    std::vector<tinfo> T;
+    std::vector<launch> L;
+    std::vector<void *> allocs;
+    std::vector<int> outputs;
+    unsigned *d_imgmax = nullptr;
+    int in_h = 0, in_w = 0;
+    int last_batch = 0;
+};
+
+static int dev_alloc(yk_plan *p, void **ptr, size_t bytes, bool zero) {
+    YK_HIP(hipMalloc(ptr, bytes));
+    p->allocs.push_back(*ptr);
+    if (zero) YK_HIP(hipMemset(*ptr, 0, bytes));
+    return YK_OK;
+}
+static int upload(yk_plan *p, void **ptr, const void *src, size_t bytes) {
+    int rc = dev_alloc(p, ptr, bytes, false);
+    if (rc) return rc;
+    YK_HIP(hipMemcpy(*ptr, src, bytes, hipMemcpyHostToDevice));
+    return YK_OK;
+}
+// scale/bias padded with zeros so the epilogue may read past N unguarded
+static int upload_sb(yk_plan *p, const float *blob, int off, int n, const float **d) {
+    std::vector<float> v((size_t)n + 256, 0.f);
+    memcpy(v.data(), blob + off, sizeof(float) * n);
+    void *q;
+    int rc = upload(p, &q, v.data(), v.size() * sizeof(float));
+    *d = (const float *)q;
+    return rc;
+}
+
+static bool env_flag(const char *name, bool dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    return e[0] != '0';
+}
+
+extern "C" void yk_plan_destroy(yk_plan_t *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (void *q : p->allocs) (void)hipFree(q);
+    delete p;
+}
+
+extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
+                              const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
+                              int device) {
+    if (!out || !ops || !tensors || !blob || !outputs || n_ops <= 0 || n_tensors <= 0 || max_batch <= 0) {
+        yk_set_error("yk_plan_create: bad argument");
+        return YK_ERR_ARG;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        yk_set_error("yk_plan_create: no HIP device visible (this library has no CPU path)");
+        return YK_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        yk_set_error("yk_plan_create: device %d out of range (%d visible)", device, ndev);
+        return YK_ERR_NO_DEVICE;
+    }
+    YK_HIP(hipSetDevice(device));
+    yk_plan *p = new yk_plan();
+    p->device = device;
+    p->max_batch = max_batch;
+    int rc = YK_OK;
+    auto fail = [&](int code) {
+        yk_plan_destroy(p);
+        return code;
+    };
+
+    p->T.resize(n_tensors);
+    for (int i = 0; i < n_tensors; ++i) {
+        tinfo &t = p->T[i];
+        t.h = tensors[4 * i];
+        t.w = tensors[4 * i + 1];
+        t.c = tensors[4 * i + 2];
+        t.cp = yk_pad8(t.c);
+        t.is_input = tensors[4 * i + 3] != 0;
+    }
+    if (!p->T[0].is_input || p->T[0].c != 3) {
+        yk_set_error("yk_plan_create: tensor 0 must be the 3-channel network input");
+        return fail(YK_ERR_UNSUPPORTED);
+    }
+    p->in_h = p->T[0].h;
+    p->in_w = p->T[0].w;
+    for (int i = 0; i < n_outputs; ++i) {
+        if (outputs[i] < 0 || outputs[i] >= n_tensors) {
+            yk_set_error("yk_plan_create: bad output id");
+            return fail(YK_ERR_ARG);
+        }
+        p->outputs.push_back(outputs[i]);
+    }
+    // pass 1: views, use counts, output flags
+    for (int i = 0; i < n_ops; ++i) {
+        const int32_t *o = ops + (size_t)i * YK_OP_FIELDS;
+        const int ty = o[YK_F_TYPE], in0 = o[YK_F_IN0], in1 = o[YK_F_IN1], ot = o[YK_F_OUT];
+        if (in0 < 0 || in0 >= n_tensors || ot <= 0 || ot >= n_tensors || in1 >= n_tensors) {
+            yk_set_error("yk_plan_create: op %d has a bad tensor id", i);
+            return fail(YK_ERR_ARG);
+        }
+        p->T[in0].uses++;
+        if (in1 >= 0) p->T[in1].uses++;
+        if (ty == YK_OP_UPSAMPLE) {
+            p->T[ot].kind = T_UP;
+            p->T[ot].src0 = in0;
+        } else if (ty == YK_OP_CONCAT) {
+            p->T[ot].kind = T_CAT;
+            p->T[ot].src0 = in0;
+            p->T[ot].src1 = in1;
+        }
+        if ((ty == YK_OP_CONV) && (o[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT)) p->T[ot].net_out = true;
+        if ((ty == YK_OP_CONV || ty == YK_OP_DWCONV) &&
+            ((size_t)std::max(o[YK_F_W_OFF], std::max(o[YK_F_SCALE_OFF], o[YK_F_BIAS_OFF])) >= blob_len ||
+             o[YK_F_W_OFF] < 0)) {
+            yk_set_error("yk_plan_create: op %d weight offset outside the blob", i);
+            return fail(YK_ERR_ARG);
+        }
+    }
+    for (int t : p->outputs) p->T[t].uses++;
+
+    // fusion decisions need the op list; decide ADD-folding first
+    std::vector<int> add_of(n_ops, -1);   // conv op i -> index of the ADD folded into it
+    std::vector<char> skip(n_ops, 0);
+    for (int i = 0; i + 1 < n_ops; ++i) {
+        const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
+        if (o[YK_F_TYPE] == YK_OP_CONV && q[YK_F_TYPE] == YK_OP_ADD && !(o[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT)) {
+            const int y = o[YK_F_OUT];
+            const int other = (q[YK_F_IN0] == y) ? q[YK_F_IN1] : (q[YK_F_IN1] == y ? q[YK_F_IN0] : -1);
+            if (other >= 0 && other != y && p->T[y].uses == 1 && p->T[other].kind == T_REAL && !p->T[other].is_input) {
+                add_of[i] = i + 1;
+                skip[i + 1] = 1;
+            }
+        }
+    }
+    // depthwise -> pointwise fusion (decided here, realised below)
+    const bool fuse_dwpw = env_flag("YK_FUSE_DWPW", true);
+    std::vector<int> dw_of(n_ops, -1);    // 1x1 conv op i -> index of the DWCONV fused in front of it
+    if (fuse_dwpw) {
+        for (int i = 0; i + 1 < n_ops; ++i) {
+            const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
+            if (o[YK_F_TYPE] == YK_OP_DWCONV && q[YK_F_TYPE] == YK_OP_CONV && q[YK_F_K] == 1 &&
+                q[YK_F_IN0] == o[YK_F_OUT] && p->T[o[YK_F_OUT]].uses == 1 && !(q[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT) &&
+                p->T[o[YK_F_IN0]].kind == T_REAL && !p->T[o[YK_F_IN0]].is_input && o[YK_F_ACT] != YK_ACT_LEAKY &&
+                yk_igemm_fused_ok(yk_pad8(o[YK_F_CIN]), q[YK_F_COUT])) {
+                dw_of[i + 1] = i;
+                skip[i] = 1;
+            }
+        }
+    }
+
+    // allocate real tensors
+    for (int i = 1; i < n_tensors; ++i) {
+        tinfo &t = p->T[i];
+        if (t.kind != T_REAL) continue;
+        bool produced_fused_away = false;
+        for (int k = 0; k < n_ops; ++k) {
+            const int32_t *o = ops + (size_t)k * YK_OP_FIELDS;
+            if (o[YK_F_OUT] == i && ((skip[k] && o[YK_F_TYPE] == YK_OP_DWCONV) || add_of[k] >= 0)) produced_fused_away = true;
+        }
+        if (produced_fused_away) continue;   // lives only in LDS / registers
+        if (t.net_out) {
+            rc = dev_alloc(p, (void **)&t.d32, (size_t)max_batch * t.h * t.w * t.c * sizeof(float), true);
+        } else {
+            rc = dev_alloc(p, (void **)&t.d, ((size_t)max_batch * t.h * t.w * t.cp + 64) * sizeof(yk_half), true);
+        }
+        if (rc) return fail(rc);
+    }
+    rc = dev_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch, true);
+    if (rc) return fail(rc);
+
+    // pass 2: launches
+    for (int i = 0; i < n_ops; ++i) {
+        if (skip[i]) continue;
+        const int32_t *o = ops + (size_t)i * YK_OP_FIELDS;
+        const int ty = o[YK_F_TYPE];
+        if (ty == YK_OP_UPSAMPLE || ty == YK_OP_CONCAT) continue;
+        const tinfo &X = p->T[o[YK_F_IN0]];
+        tinfo &Y = p->T[o[YK_F_OUT]];
+        float alpha;
+        memcpy(&alpha, &o[YK_F_ALPHA], 4);
+        launch l;
+        l.Ho = Y.h;
+        l.Wo = Y.w;
+        char nm[96];
+        if (ty == YK_OP_CONV && X.is_input) {
+            // ---- stem conv
+            if (o[YK_F_K] != 3 || add_of[i] >= 0 || Y.net_out) {
+                yk_set_error("op %d: stem conv must be 3x3", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            const int co = o[YK_F_COUT];
+            std::vector<float> w((size_t)27 * co);
+            for (int c = 0; c < co; ++c)
+                for (int t = 0; t < 27; ++t) w[(size_t)t * co + c] = h2f_bits(f2h_bits(blob[o[YK_F_W_OFF] + (size_t)c * 27 + t]));
+            void *dw_;
+            if ((rc = upload(p, &dw_, w.data(), w.size() * sizeof(float)))) return fail(rc);
+            l.kind = K_FIRST;
+            first_args &f = l.f;
+            memset(&f, 0, sizeof(f));
+            f.Hi = X.h; f.Wi = X.w; f.Ho = Y.h; f.Wo = Y.w;
+            f.stride = o[YK_F_STRIDE]; f.pad_t = o[YK_F_PAD_T]; f.pad_l = o[YK_F_PAD_L];
+            f.Cout = co; f.outp = Y.cp; f.w = (const float *)dw_;
+            if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &f.scale))) return fail(rc);
+            if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &f.bias))) return fail(rc);
+            f.act = o[YK_F_ACT]; f.alpha = alpha; f.out = Y.d;
+            if (Y.cp != co) {
+                yk_set_error("op %d: stem conv Cout must be a multiple of 8", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            snprintf(nm, sizeof nm, "stem3x3s%d_%d", f.stride, co);
+            l.flops = 2.0 * Y.h * Y.w * 27 * co;
+            l.bytes = (double)X.h * X.w * 3 * 2 + (double)Y.h * Y.w * co * 2;
+        } else if (ty == YK_OP_CONV) {
+            // ---- implicit GEMM conv (+ folded Add, + fused depthwise producer)
+            l.kind = K_IGEMM;
+            igemm_args &g = l.g;
+            memset(&g, 0, sizeof(g));
+            const tinfo *s0 = &X, *s1 = nullptr;
+            int up0 = 0;
+            if (X.kind == T_CAT) {
+                s0 = &p->T[X.src0];
+                s1 = &p->T[X.src1];
+            }
+            if (s0->kind == T_UP) {
+                up0 = 1;
+                s0 = &p->T[s0->src0];
+            }
+            const int dwi = dw_of[i];
+            const int32_t *dwo = dwi >= 0 ? ops + (size_t)dwi * YK_OP_FIELDS : nullptr;
+            const tinfo *dwX = dwo ? &p->T[dwo[YK_F_IN0]] : nullptr;
+            if (dwo) s0 = dwX;
+            if (s0->kind != T_REAL || (s1 && s1->kind != T_REAL) || s0->is_input || (s1 && s1->is_input) || !s0->d ||
+                (s1 && !s1->d)) {
+                yk_set_error("op %d: unsupported input view nesting", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            const int ks = o[YK_F_K], co = o[YK_F_COUT];
+            const int c0 = dwo ? X.c : s0->c, c0p = yk_pad8(c0), c1 = s1 ? s1->c : 0, c1p = s1 ? s1->cp : 0;
+            if (c0 + c1 != o[YK_F_CIN] || (ks != 1 && ks != 3)) {
+                yk_set_error("op %d: conv shape mismatch (cin %d vs %d+%d, k=%d)", i, o[YK_F_CIN], c0, c1, ks);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            g.in0 = s0->d; g.in1 = s1 ? s1->d : nullptr;
+            g.c0p = c0p; g.c1p = c1p; g.up0 = up0;
+            g.Hi = X.h; g.Wi = X.w; g.Ho = Y.h; g.Wo = Y.w;
+            g.ks = ks; g.stride = o[YK_F_STRIDE]; g.pad_t = o[YK_F_PAD_T]; g.pad_l = o[YK_F_PAD_L];
+            g.N = co; g.K = ks * ks * (c0p + c1p);
+            std::vector<uint16_t> w((size_t)co * g.K, 0);
+            const int cin = o[YK_F_CIN];
+            for (int n = 0; n < co; ++n)
+                for (int t = 0; t < ks * ks; ++t)
+                    for (int c = 0; c < cin; ++c) {
+                        const int pos = c < c0 ? c : c0p + (c - c0);
+                        w[(size_t)n * g.K + (size_t)t * (c0p + c1p) + pos] =
+                            f2h_bits(blob[o[YK_F_W_OFF] + ((size_t)n * ks * ks + t) * cin + c]);
+                    }
+            void *dwt;
+            if ((rc = upload(p, &dwt, w.data(), w.size() * 2))) return fail(rc);
+            g.w = (const yk_half *)dwt;
+            if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &g.scale))) return fail(rc);
+            if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &g.bias))) return fail(rc);
+            g.act = o[YK_F_ACT]; g.alpha = alpha;
+            tinfo *dst = &Y;
+            if (add_of[i] >= 0) {
+                const int32_t *q = ops + (size_t)add_of[i] * YK_OP_FIELDS;
+                const int other = (q[YK_F_IN0] == o[YK_F_OUT]) ? q[YK_F_IN1] : q[YK_F_IN0];
+                g.res = p->T[other].d;
+                g.resp = p->T[other].cp;
+                dst = &p->T[q[YK_F_OUT]];
+            }
+            const bool f32 = dst->net_out;
+            g.out = f32 ? (void *)dst->d32 : (void *)dst->d;
+            g.outp = f32 ? dst->c : dst->cp;
+            if (!g.out) {
+                yk_set_error("op %d: output tensor not allocated", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            double dw_flops = 0, dw_bytes = 0;
+            if (dwo) {
+                float dalpha;
+                memcpy(&dalpha, &dwo[YK_F_ALPHA], 4);
+                (void)dalpha;
+                std::vector<uint16_t> dww((size_t)9 * c0p, 0);
+                for (int t = 0; t < 9; ++t)
+                    for (int c = 0; c < c0; ++c) dww[(size_t)t * c0p + c] = f2h_bits(blob[dwo[YK_F_W_OFF] + (size_t)t * c0 + c]);
+                void *dd;
+                if ((rc = upload(p, &dd, dww.data(), dww.size() * 2))) return fail(rc);
+                g.dw_w = (const yk_half *)dd;
+                if ((rc = upload_sb(p, blob, dwo[YK_F_SCALE_OFF], c0, &g.dw_scale))) return fail(rc);
+                if ((rc = upload_sb(p, blob, dwo[YK_F_BIAS_OFF], c0, &g.dw_bias))) return fail(rc);
+                g.dw_act = dwo[YK_F_ACT]; g.dw_stride = dwo[YK_F_STRIDE];
+                g.dw_pad_t = dwo[YK_F_PAD_T]; g.dw_pad_l = dwo[YK_F_PAD_L];
+                g.dw_Hi = dwX->h; g.dw_Wi = dwX->w;
+                dw_flops = 2.0 * X.h * X.w * 9 * c0;
+                dw_bytes = ((double)dwX->h * dwX->w * c0 + (double)X.h * X.w * c0) * 2;
+            }
+            g.M = max_batch * Y.h * Y.w;   // for config choice; patched per run
+            l.cfg = dwo ? yk_igemm_fused_pick(g) : yk_igemm_pick(g, f32);
+            snprintf(nm, sizeof nm, "%sconv%dx%ds%d_%dto%d%s%s[%s]", dwo ? "dw3x3+" : "", ks, ks, g.stride, o[YK_F_CIN], co,
+                     g.res ? "+add" : "", s1 ? "+upcat" : (up0 ? "+up" : ""),
+                     dwo ? yk_igemm_fused_name(l.cfg) : yk_igemm_name(l.cfg));
+            l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)o[YK_F_CIN] * co + dw_flops;
+            l.bytes = ((double)X.h * X.w * o[YK_F_CIN] + (double)Y.h * Y.w * co) * 2 + dw_bytes;
+        } else if (ty == YK_OP_DWCONV) {
+            if (X.kind != T_REAL || X.is_input) {
+                yk_set_error("op %d: depthwise conv on a view/input", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            l.kind = K_DW;
+            dw_args &d = l.d;
+            memset(&d, 0, sizeof(d));
+            const int c = X.c, cp = X.cp;
+            std::vector<uint16_t> w((size_t)9 * cp, 0);
+            for (int t = 0; t < 9; ++t)
+                for (int k = 0; k < c; ++k) w[(size_t)t * cp + k] = f2h_bits(blob[o[YK_F_W_OFF] + (size_t)t * c + k]);
+            void *dd;
+            if ((rc = upload(p, &dd, w.data(), w.size() * 2))) return fail(rc);
+            d.in = X.d; d.Hi = X.h; d.Wi = X.w; d.Ho = Y.h; d.Wo = Y.w; d.Cp = cp;
+            d.stride = o[YK_F_STRIDE]; d.pad_t = o[YK_F_PAD_T]; d.pad_l = o[YK_F_PAD_L];
+            d.w = (const yk_half *)dd;
+            if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], c, &d.scale))) return fail(rc);
+            if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], c, &d.bias))) return fail(rc);
+            d.act = o[YK_F_ACT]; d.alpha = alpha; d.out = Y.d;
+            snprintf(nm, sizeof nm, "dw3x3s%d_%d", d.stride, c);
+            l.flops = 2.0 * Y.h * Y.w * 9 * c;
+            l.bytes = ((double)X.h * X.w * c + (double)Y.h * Y.w * c) * 2;
+        } else if (ty == YK_OP_MAXPOOL) {
+            if (X.kind != T_REAL || X.is_input) {
+                yk_set_error("op %d: max pool on a view/input", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            l.kind = K_POOL;
+            pool_args &q = l.p;
+            memset(&q, 0, sizeof(q));
+            q.in = X.d; q.Hi = X.h; q.Wi = X.w; q.Ho = Y.h; q.Wo = Y.w; q.Cp = X.cp; q.stride = o[YK_F_STRIDE]; q.out = Y.d;
+            snprintf(nm, sizeof nm, "maxpool2x2s%d_%d", q.stride, X.c);
+            l.bytes = ((double)X.h * X.w * X.c + (double)Y.h * Y.w * Y.c) * 2;
+        } else if (ty == YK_OP_ADD) {
+            const tinfo &Z = p->T[o[YK_F_IN1]];
+            if (X.kind != T_REAL || Z.kind != T_REAL || !X.d || !Z.d || !Y.d) {
+                yk_set_error("op %d: standalone Add on views", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            l.kind = K_ADD;
+            l.add_a = X.d; l.add_b = Z.d; l.add_o = Y.d;
+            l.add_n8_per_image = (size_t)Y.h * Y.w * Y.cp / 8;
+            snprintf(nm, sizeof nm, "add_%d", Y.c);
+            l.bytes = 3.0 * Y.h * Y.w * Y.c * 2;
+        } else {
+            yk_set_error("op %d: unknown op type %d", i, ty);
+            return fail(YK_ERR_UNSUPPORTED);
+        }
+        l.name = nm;
+        p->L.push_back(l);
+    }
+    for (int t : p->outputs)
+        if (!p->T[t].d32) {
+            yk_set_error("yk_plan_create: output tensor %d is not produced by a NET_OUTPUT conv", t);
+            return fail(YK_ERR_UNSUPPORTED);
+        }
+    YK_HIP(hipDeviceSynchronize());
+    *out = p;
+    return YK_OK;
+}
+
+static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *stream) {
+    if (!p || !d_in || batch <= 0 || batch > p->max_batch) {
+        yk_set_error("yk_run: bad plan/input/batch (max_batch=%d)", p ? p->max_batch : 0);
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!in_f32) {
+        YK_HIP(hipMemsetAsync(p->d_imgmax, 0, sizeof(unsigned) * batch, st));
+        yk_launch_u8_max((const uint8_t *)d_in, (size_t)p->in_h * p->in_w * 3, batch, p->d_imgmax, st);
+    }
+    for (launch &l : p->L) {
+        int rc = YK_OK;
+        switch (l.kind) {
+        case K_FIRST: {
+            first_args f = l.f;
+            f.in = d_in; f.in_f32 = in_f32; f.img_max = p->d_imgmax; f.B = batch;
+            rc = yk_launch_first(f, st);
+        } break;
+        case K_IGEMM: {
+            igemm_args g = l.g;
+            g.M = batch * l.Ho * l.Wo;
+            rc = g.dw_w ? yk_launch_igemm_fused(l.cfg, g, st) : yk_launch_igemm(l.cfg, g, st);
+        } break;
+        case K_DW: {
+            dw_args d = l.d;
+            d.B = batch;
+            rc = yk_launch_dw(d, st);
+        } break;
+        case K_POOL: {
+            pool_args q = l.p;
+            q.B = batch;
+            rc = yk_launch_pool(q, st);
+        } break;
+        case K_ADD: rc = yk_launch_add(l.add_a, l.add_b, l.add_o, l.add_n8_per_image * batch, st); break;
+        }
+        if (rc) return rc;
+    }
+    YK_HIP(hipGetLastError());
+    p->last_batch = batch;
+    return YK_OK;
+}
+
+extern "C" int yk_run_u8(yk_plan_t *p, const uint8_t *d_frames, int batch, void *stream) {
+    return run_plan(p, d_frames, 0, batch, stream);
+}
+extern "C" int yk_run_f32(yk_plan_t *p, const float *d_input, int batch, void *stream) {
+    return run_plan(p, d_input, 1, batch, stream);
+}
+
+extern "C" int yk_get_output(yk_plan_t *p, int idx, float **d_ptr, size_t *bytes, int *h, int *w, int *c) {
+    if (!p || idx < 0 || idx >= (int)p->outputs.size()) {
+        yk_set_error("yk_get_output: bad index");
+        return YK_ERR_ARG;
+    }
+    const tinfo &t = p->T[p->outputs[idx]];
+    if (d_ptr) *d_ptr = t.d32;
+    if (bytes) *bytes = (size_t)p->max_batch * t.h * t.w * t.c * sizeof(float);
+    if (h) *h = t.h;
+    if (w) *w = t.w;
+    if (c) *c = t.c;
+    return YK_OK;
+}
+
+extern "C" int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_dst, size_t dst_elems) {
+    if (!p || tid <= 0 || tid >= (int)p->T.size() || batch <= 0 || batch > p->max_batch || !h_dst) {
+        yk_set_error("yk_debug_read_tensor: bad argument");
+        return YK_ERR_ARG;
+    }
+    const tinfo &t = p->T[tid];
+    const size_t n = (size_t)batch * t.h * t.w * t.c;
+    if (dst_elems < n) {
+        yk_set_error("yk_debug_read_tensor: destination too small");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipSetDevice(p->device));
+    YK_HIP(hipDeviceSynchronize());
+    if (t.d32) {
+        YK_HIP(hipMemcpy(h_dst, t.d32, n * sizeof(float), hipMemcpyDeviceToHost));
+        return YK_OK;
+    }
+    if (!t.d) {
+        yk_set_error("yk_debug_read_tensor: tensor %d is a view or was fused away", tid);
+        return YK_ERR_UNSUPPORTED;
+    }
+    std::vector<uint16_t> h((size_t)batch * t.h * t.w * t.cp);
+    YK_HIP(hipMemcpy(h.data(), t.d, h.size() * 2, hipMemcpyDeviceToHost));
+    const size_t pix = (size_t)batch * t.h * t.w;
+    for (size_t q = 0; q < pix; ++q)
+        for (int c = 0; c < t.c; ++c) h_dst[q * t.c + c] = h2f_bits(h[q * t.cp + c]);
+    return YK_OK;
+}
+
+extern "C" int yk_plan_launch_count(const yk_plan_t *p) { return p ? (int)p->L.size() : 0; }
+
+extern "C" int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, double *flops_per_image,
+                                   double *bytes_per_image) {
+    if (!p || i < 0 || i >= (int)p->L.size()) return YK_ERR_ARG;
+    if (name && name_len) snprintf(name, name_len, "%s", p->L[i].name.c_str());
+    if (flops_per_image) *flops_per_image = p->L[i].flops;
+    if (bytes_per_image) *bytes_per_image = p->L[i].bytes;
+    return YK_OK;
+}

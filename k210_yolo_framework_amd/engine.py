@@ -1,0 +1,241 @@
+"""ctypes binding of libyolo_hip.so (include/yolo_hip.h) — the ONLY compute path of this package.
+
+There is no CPU fallback: if the library is missing, or no HIP device is visible, every entry point
+raises.  PyTorch-ROCm is used for plumbing only (device buffers, streams, torch.distributed); it is
+imported before the library so that both share one HIP runtime instance (libamdhip64.so.7).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import netspec as ns
+
+LIB_PATH = Path(__file__).resolve().parent / 'csrc' / 'libyolo_hip.so'
+YK_MAX_LAYERS, YK_MAX_ANCHORS = 4, 8
+_lib: Optional[C.CDLL] = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+class YkError(RuntimeError):
+    pass
+
+
+class DecodeCfg(C.Structure):
+    """yk_decode_cfg_t"""
+    _fields_ = [('n_layers', C.c_int32), ('anchor_num', C.c_int32), ('class_num', C.c_int32),
+                ('in_h', C.c_int32), ('in_w', C.c_int32),
+                ('out_h', C.c_int32 * YK_MAX_LAYERS), ('out_w', C.c_int32 * YK_MAX_LAYERS),
+                ('anchors', (C.c_float * 2) * YK_MAX_ANCHORS * YK_MAX_LAYERS)]
+
+
+class RegionCfg(C.Structure):
+    """yk_region_cfg_t"""
+    _fields_ = [('layer_w', C.c_int32), ('layer_h', C.c_int32), ('anchor_num', C.c_int32), ('classes', C.c_int32),
+                ('net_w', C.c_int32), ('net_h', C.c_int32), ('image_w', C.c_int32), ('image_h', C.c_int32),
+                ('threshold', C.c_float), ('nms_value', C.c_float), ('anchor', C.c_float * (2 * YK_MAX_ANCHORS)),
+                ('stride_b', C.c_int64), ('stride_n', C.c_int64), ('stride_e', C.c_int64),
+                ('stride_y', C.c_int64), ('stride_x', C.c_int64)]
+
+
+def library_path() -> Path:
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load libyolo_hip.so (after torch, so the HIP runtime is shared).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise YkError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        import torch  # noqa: F401  (binds libamdhip64.so.7 first)
+        L = C.CDLL(str(LIB_PATH))
+        L.yk_last_error.restype = C.c_char_p
+        L.yk_device_count.restype = C.c_int
+        for fn in ('yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_decode_py', 'yk_region_batched',
+                   'region_layer_init'):
+            getattr(L, fn).restype = C.c_int
+        L.yk_plan_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise YkError(f'{what} failed ({rc}): {lib().yk_last_error().decode()}')
+
+
+def require_gpu() -> None:
+    import torch
+    if not torch.cuda.is_available() or lib().yk_device_count() <= 0:
+        raise YkError('no MI355X / HIP device visible: the HIP path is the only path (no CPU fallback)')
+
+
+def _ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(stream=None) -> C.c_void_p:
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+class _DevView:
+    """Zero-copy torch view of library-owned device memory via __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = {'shape': tuple(int(s) for s in shape), 'typestr': typestr,
+                                         'data': (int(ptr), False), 'version': 2}
+        self._owner = owner
+
+
+class Plan:
+    """kpu_load_kmodel analogue (main.c:274): a compiled, device-resident network."""
+
+    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None):
+        import torch
+        require_gpu()
+        self.spec = spec
+        self.max_batch = int(max_batch)
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        ops, tens, blob = spec.compile_plan(weights)
+        self._ops = np.ascontiguousarray(ops, np.int32)
+        self._tens = np.ascontiguousarray(tens, np.int32)
+        blob = np.ascontiguousarray(blob, np.float32)
+        outs = np.ascontiguousarray(spec.outputs, np.int32)
+        self._h = C.c_void_p()
+        L = lib()
+        _check(L.yk_plan_create(C.byref(self._h), self._ops.ctypes.data_as(i32p), C.c_int(len(ops)),
+                                self._tens.ctypes.data_as(i32p), C.c_int(len(tens)), blob.ctypes.data_as(f32p),
+                                C.c_size_t(blob.size), outs.ctypes.data_as(i32p), C.c_int(len(outs)),
+                                C.c_int(self.max_batch), C.c_int(self.device)), 'yk_plan_create')
+        self._out_views = None
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            lib().yk_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- run ---------------------------------------------------------------
+    def run_u8(self, frames, stream=None) -> None:
+        """frames: torch.uint8 cuda tensor [B,H,W,3] (kpu_run_kmodel analogue, async)."""
+        assert frames.is_cuda and frames.dtype.__str__() == 'torch.uint8' and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (*self.spec.in_hw, 3), frames.shape
+        _check(lib().yk_run_u8(self._h, _ptr(frames), C.c_int(frames.shape[0]), _stream(stream)), 'yk_run_u8')
+
+    def run_f32(self, x, stream=None) -> None:
+        assert x.is_cuda and x.dtype.__str__() == 'torch.float32' and x.is_contiguous()
+        assert tuple(x.shape[1:]) == (*self.spec.in_hw, 3), x.shape
+        _check(lib().yk_run_f32(self._h, _ptr(x), C.c_int(x.shape[0]), _stream(stream)), 'yk_run_f32')
+
+    def output_ptrs(self) -> List[Tuple[int, Tuple[int, int, int]]]:
+        res = []
+        for i in range(len(self.spec.outputs)):
+            p = f32p()
+            nb = C.c_size_t()
+            h, w, c = C.c_int(), C.c_int(), C.c_int()
+            _check(lib().yk_get_output(self._h, C.c_int(i), C.byref(p), C.byref(nb), C.byref(h), C.byref(w), C.byref(c)),
+                   'yk_get_output')
+            res.append((C.cast(p, C.c_void_p).value, (h.value, w.value, c.value)))
+        return res
+
+    def outputs(self):
+        """Borrowed torch views [max_batch,h,w,A*(5+C)] fp32 of the network outputs (kpu_get_output)."""
+        import torch
+        if self._out_views is None:
+            self._out_views = [torch.as_tensor(_DevView(p, (self.max_batch, *s), '<f4', self), device=f'cuda:{self.device}')
+                               for p, s in self.output_ptrs()]
+        return self._out_views
+
+    def read_tensor(self, tid: int, batch: int) -> np.ndarray:
+        h, w, c = self.spec.tensors[tid]
+        out = np.empty((batch, h, w, c), np.float32)
+        _check(lib().yk_debug_read_tensor(self._h, C.c_int(tid), C.c_int(batch), out.ctypes.data_as(f32p),
+                                          C.c_size_t(out.size)), 'yk_debug_read_tensor')
+        return out
+
+    def launches(self):
+        n = lib().yk_plan_launch_count(self._h)
+        res = []
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            fl, by = C.c_double(), C.c_double()
+            lib().yk_plan_launch_info(self._h, C.c_int(i), name, C.c_size_t(128), C.byref(fl), C.byref(by))
+            res.append((name.value.decode(), fl.value, by.value))
+        return res
+
+
+def make_decode_cfg(anchors: np.ndarray, class_num: int, in_hw, out_hw) -> DecodeCfg:
+    anchors = np.asarray(anchors, np.float32)
+    L, A = anchors.shape[0], anchors.shape[1]
+    if L > YK_MAX_LAYERS or A > YK_MAX_ANCHORS:
+        raise YkError('too many layers/anchors')
+    cfg = DecodeCfg()
+    cfg.n_layers, cfg.anchor_num, cfg.class_num = L, A, int(class_num)
+    cfg.in_h, cfg.in_w = int(in_hw[0]), int(in_hw[1])
+    for l in range(L):
+        cfg.out_h[l], cfg.out_w[l] = int(out_hw[l][0]), int(out_hw[l][1])
+        for n in range(A):
+            cfg.anchors[l][n][0] = float(anchors[l, n, 0])
+            cfg.anchors[l][n][1] = float(anchors[l, n, 1])
+    return cfg
+
+
+def decode_py(cfg: DecodeCfg, preds: Sequence, batch: int, image_hw=None, obj_thresh: float = 0.7,
+              iou_thresh: float = 0.5, max_out: int = 30, stream=None):
+    """Batched keras_inference.py:94-135 on the GPU.  preds: cuda fp32 tensors [>=batch,h,w,A*(5+C)].
+    -> (dets [batch, C*max_out, 6] cuda fp32, counts [batch] cuda int32)."""
+    import torch
+    require_gpu()
+    dev = preds[0].device
+    dets = torch.empty((batch, cfg.class_num * max_out, 6), dtype=torch.float32, device=dev)
+    counts = torch.empty((batch,), dtype=torch.int32, device=dev)
+    arr = (C.c_void_p * len(preds))(*[C.c_void_p(p.data_ptr()) for p in preds])
+    ihw = None
+    if image_hw is not None:
+        ihw = torch.as_tensor(np.broadcast_to(np.asarray(image_hw, np.float32), (batch, 2)).copy(), device=dev)
+    _check(lib().yk_decode_py(C.byref(cfg), arr, C.c_int(batch), _ptr(ihw) if ihw is not None else None,
+                              C.c_float(obj_thresh), C.c_float(iou_thresh), C.c_int(max_out), _ptr(dets), _ptr(counts),
+                              _stream(stream)), 'yk_decode_py')
+    return dets, counts
+
+
+def region_batched(inp, W: int, H: int, A: int, Cn: int, anchor, threshold: float, nms_value: float,
+                   net_wh=(320, 224), image_wh=(320, 224), layout: str = 'chw', want_output: bool = True, stream=None):
+    """Batched C-mode region layer.  inp: cuda fp32 [B, A*(5+C), H, W] ('chw') or [B,H,W,A*(5+C)] ('hwc').
+    -> (output|None, boxes [B,nb,4], probs [B,nb,C+1])."""
+    import torch
+    require_gpu()
+    B = inp.shape[0]
+    E, hw, nb = 5 + Cn, W * H, A * W * H
+    cfg = RegionCfg()
+    cfg.layer_w, cfg.layer_h, cfg.anchor_num, cfg.classes = W, H, A, Cn
+    cfg.net_w, cfg.net_h, cfg.image_w, cfg.image_h = net_wh[0], net_wh[1], image_wh[0], image_wh[1]
+    cfg.threshold, cfg.nms_value = threshold, nms_value
+    for i, v in enumerate(np.asarray(anchor, np.float32).ravel()):
+        cfg.anchor[i] = float(v)
+    if layout == 'chw':
+        cfg.stride_b, cfg.stride_n, cfg.stride_e, cfg.stride_y, cfg.stride_x = A * E * hw, E * hw, hw, W, 1
+    else:
+        cfg.stride_b, cfg.stride_n, cfg.stride_e, cfg.stride_y, cfg.stride_x = A * E * hw, E, 1, W * A * E, A * E
+    out = torch.empty((B, A * E, H, W), dtype=torch.float32, device=inp.device) if want_output else None
+    boxes = torch.empty((B, nb, 4), dtype=torch.float32, device=inp.device)
+    probs = torch.empty((B, nb, Cn + 1), dtype=torch.float32, device=inp.device)
+    _check(lib().yk_region_batched(C.byref(cfg), _ptr(inp), C.c_int(B), _ptr(out) if out is not None else None,
+                                   _ptr(boxes), _ptr(probs), _stream(stream)), 'yk_region_batched')
+    return out, boxes, probs

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/yolo_hip.h declares; struct layouts match region_layer.h:7-39; no compute calls (no GPU here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = ROOT / 'include' / 'yolo_hip.h'
+LIB = ROOT / 'k210_yolo_framework_amd' / 'csrc' / 'libyolo_hip.so'
+
+
+def declared_functions():
+    txt = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)
+    txt = re.sub(r'typedef\s+void\s*\(\*\w+\)\s*\([^;]*?\);', '', txt, flags=re.S)   # callback typedef is not an export
+    names = re.findall(r'^\s*(?:const\s+)?(?:int|void|char|size_t)\s*\*?\s*(\w+)\s*\(', txt, flags=re.M)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope='module')
+def dll():
+    if not LIB.exists():
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(str(LIB))
+
+
+def test_header_declares_the_reference_abi():
+    fns = declared_functions()
+    for f in ('region_layer_init', 'region_layer_deinit', 'region_layer_run', 'region_layer_draw_boxes',   # region_layer.h:44-48
+              'yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_decode_py', 'yk_region_batched'):
+        assert f in fns
+
+
+def test_library_exports_every_declared_symbol(dll):
+    for f in declared_functions():
+        assert hasattr(dll, f), f'libyolo_hip.so does not export {f}'
+
+
+def test_struct_layouts_match_reference_header():
+    import oracle
+    rl = oracle.RegionLayerT
+    # region_layer.h:19-39 on LP64: 2 floats, 2 u32, ptr @16, 9 u32 (+4 pad), 5 pointers @64..96
+    assert C.sizeof(rl) == 104
+    assert rl.anchor.offset == 16 and rl.image_width.offset == 24 and rl.boxes.offset == 64
+    assert rl.input.offset == 72 and rl.probs.offset == 96
+    from k210_yolo_framework_amd import engine
+    assert C.sizeof(engine.DecodeCfg) == 5 * 4 + 2 * 4 * 4 + 4 * 8 * 2 * 4
+    assert C.sizeof(engine.RegionCfg) == 8 * 4 + 2 * 4 + 16 * 4 + 5 * 8
+
+
+def test_no_gpu_means_loud_failure(dll):
+    """Without a HIP device the product must refuse, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    dll.yk_device_count.restype = C.c_int
+    assert dll.yk_device_count() == 0
+    from k210_yolo_framework_amd import engine, netspec
+    with pytest.raises(engine.YkError):
+        engine.require_gpu()
+    s = netspec.yolo_mobilev1((32, 32, 3), 3, 2, alpha=0.5)
+    with pytest.raises(engine.YkError):
+        engine.Plan(s, s.init_weights(), max_batch=1)
+    rl = __import__('oracle').RegionLayerT()
+    anc = (C.c_float * 6)(*[0.5] * 6)
+    rl.anchor_number, rl.anchor, rl.threshold, rl.nms_value = 3, anc, 0.6, 0.3
+    dll.region_layer_init.restype = C.c_int
+    assert dll.region_layer_init(C.byref(rl), 10, 7, 75, 320, 224) == -5

@@ -1,0 +1,100 @@
+"""GPU parity: batched Python-mode decode + per-class NMS (yk_decode_py) vs oracle/decode_ref.py."""
+import numpy as np
+import pytest
+
+from oracle import decode_ref as dr
+
+pytestmark = pytest.mark.gpu
+
+ANCHORS = np.array([[[0.76120044, 0.57155991], [0.6923348, 0.88535553], [0.47163042, 0.34163313]],
+                    [[0.33340788, 0.70065861], [0.18124964, 0.38986752], [0.08497349, 0.1527057]]])
+
+
+def _preds(rng, B, hw, C, kind):
+    out = []
+    for (h, w) in hw:
+        if kind == 'uniform':
+            p = rng.uniform(-6, 6, (B, h, w, 3, 5 + C)).astype(np.float32)
+        else:
+            p = rng.normal(0, 1, (B, h, w, 3, 5 + C)).astype(np.float32)
+            p[..., 4] = rng.normal(-4, 2, (B, h, w, 3))
+            for b in range(B):
+                for _ in range(5):
+                    y, x, a, c = rng.integers(h), rng.integers(w), rng.integers(3), rng.integers(C)
+                    p[b, y, x, :, 4] = rng.uniform(3, 7, 3)
+                    p[b, y, x, :, 5 + c] = rng.uniform(3, 7, 3)
+                    p[b, y, min(x + 1, w - 1), a, 4] = 6
+                    p[b, y, min(x + 1, w - 1), a, 5 + c] = 6
+        out.append(p)
+    return out
+
+
+def _run(preds, anchors, in_hw, image_hw, obj, iou, max_out=30):
+    import torch
+    from k210_yolo_framework_amd import engine
+    engine.require_gpu()
+    B = preds[0].shape[0]
+    C = preds[0].shape[-1] - 5
+    cfg = engine.make_decode_cfg(anchors, C, in_hw, [p.shape[1:3] for p in preds])
+    dev = [torch.from_numpy(p.reshape(B, p.shape[1], p.shape[2], -1)).cuda() for p in preds]
+    dets, counts = engine.decode_py(cfg, dev, B, image_hw, obj, iou, max_out)
+    torch.cuda.synchronize()
+    return dets.cpu().numpy(), counts.cpu().numpy()
+
+
+@pytest.mark.parametrize('kind,obj,iou,image_hw', [
+    ('typical', 0.7, 0.5, None), ('uniform', 0.7, 0.5, None), ('typical', 0.7, 0.3, (374, 499)),
+    ('uniform', 0.3, 0.45, (480, 640)), ('uniform', 0.05, 0.5, None)])
+def test_decode_batch_vs_oracle(kind, obj, iou, image_hw):
+    rng = np.random.default_rng(abs(hash((kind, obj))) % 2 ** 31)
+    B = 6
+    preds = _preds(rng, B, [(7, 10), (14, 20)], 20, kind)
+    dets, counts = _run(preds, ANCHORS, (224, 320), image_hw, obj, iou)
+    ref = dr.decode_batch(preds, ANCHORS, (224, 320), image_hw if image_hw else (224, 320), obj, iou)
+    total = 0
+    for b in range(B):
+        rd, _ = ref[b]
+        assert counts[b] == len(rd), (b, counts[b], len(rd))
+        d = dets[b, :counts[b]]
+        assert np.array_equal(d[:, 5], rd[:, 5])                                  # classes, class-major order
+        np.testing.assert_allclose(d[:, 4], rd[:, 4], rtol=1e-5, atol=1e-6)       # scores
+        np.testing.assert_allclose(d[:, :4], rd[:, :4], rtol=1e-5, atol=1e-3)     # pixels of the original image
+        total += len(rd)
+    assert total > 0
+
+
+def test_decode_per_image_shapes_and_three_scales():
+    rng = np.random.default_rng(5)
+    B = 3
+    anchors = rng.uniform(0.05, 0.8, (3, 3, 2))
+    preds = _preds(rng, B, [(13, 13), (26, 26), (52, 52)], 4, 'typical')
+    ihw = np.array([[416, 416], [300, 500], [720, 405]], np.float32)
+    dets, counts = _run(preds, anchors, (416, 416), ihw, 0.6, 0.4)
+    ref = dr.decode_batch(preds, anchors, (416, 416), ihw, 0.6, 0.4)
+    for b in range(B):
+        rd, _ = ref[b]
+        assert counts[b] == len(rd)
+        d = dets[b, :counts[b]]
+        assert np.array_equal(d[:, 5], rd[:, 5])
+        np.testing.assert_allclose(d[:, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
+
+
+def test_cap_30_per_class_and_overflow_path():
+    """every box passes for class 0 (1050 candidates ... and > 2048 with 3 scales): max_output_size honoured."""
+    rng = np.random.default_rng(9)
+    preds = [rng.uniform(-1, 1, (1, h, w, 3, 6)).astype(np.float32) for (h, w) in [(13, 13), (26, 26), (52, 52)]]
+    for p in preds:
+        p[..., 4] = 8
+        p[..., 5] = rng.uniform(3, 9, p.shape[:-1])
+        p[..., 2:4] = -3
+    anchors = np.full((3, 3, 2), 0.05)
+    dets, counts = _run(preds, anchors, (416, 416), None, 0.5, 0.5)
+    rd, _ = dr.decode_batch(preds, anchors, (416, 416), (416, 416), 0.5, 0.5)[0]
+    assert counts[0] == len(rd) == 30
+    np.testing.assert_allclose(dets[0, :30, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
+
+
+def test_no_detections():
+    preds = [np.full((2, 7, 10, 3, 25), -9, np.float32), np.full((2, 14, 20, 3, 25), -9, np.float32)]
+    dets, counts = _run(preds, ANCHORS, (224, 320), None, 0.7, 0.5)
+    assert counts.tolist() == [0, 0]

@@ -1,0 +1,65 @@
+"""Independent torch-CPU arbiter for the conv stack (NOT the oracle, NOT the product).
+
+Builds the forward pass straight from Keras-layout parameters with torch.nn.functional ops
+and UNFOLDED BatchNorm, so it shares no code with netspec.compile_plan's folding, with
+oracle/yolo_net_ref.c, or with the HIP engine."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from k210_yolo_framework_amd import netspec as ns
+
+
+def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None):
+    """-> dict tensor_id -> NHWC fp32 numpy for ids in `want` (default: spec.outputs)."""
+    want = list(spec.outputs if want is None else want)
+    lay = {l.name: l for l in spec.layers}
+    T = {0: torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).double()}
+    with torch.no_grad():
+        for op in spec.ops:
+            x = T[op['in0']]
+            t = op['type']
+            if t in (ns.OP_CONV, ns.OP_DWCONV):
+                l = lay[op['layer']]
+                k = torch.from_numpy(weights[l.name + '/kernel']).double()
+                hi, wi = x.shape[2], x.shape[3]
+                ho, wo, _ = spec.tensors[op['out']]
+                kk, st = op['k'], op['stride']
+                pb = (ho - 1) * st + kk - hi - op['pad_t']
+                pr = (wo - 1) * st + kk - wi - op['pad_l']
+                xp = F.pad(x, (op['pad_l'], max(pr, 0), op['pad_t'], max(pb, 0)))
+                if t == ns.OP_CONV:
+                    w = k.permute(3, 2, 0, 1)                       # HWIO -> OIHW
+                    b = torch.from_numpy(weights[l.name + '/bias']).double() if l.use_bias else None
+                    y = F.conv2d(xp, w, b, stride=st)
+                else:
+                    w = k.permute(2, 3, 0, 1)                       # [3,3,C,1] -> [C,1,3,3]
+                    y = F.conv2d(xp, w, None, stride=st, groups=x.shape[1])
+                y = y[:, :, :ho, :wo]
+                if l.bn_name:
+                    g, bt, mu, var = (torch.from_numpy(weights[l.bn_name + s]).double()
+                                      for s in ('/gamma', '/beta', '/moving_mean', '/moving_variance'))
+                    y = F.batch_norm(y, mu, var, g, bt, training=False, eps=ns.BN_EPS)
+                a = op['act']
+                if a == ns.ACT_RELU:
+                    y = F.relu(y)
+                elif a == ns.ACT_RELU6:
+                    y = torch.clamp(y, 0, 6)
+                elif a == ns.ACT_LEAKY:
+                    y = F.leaky_relu(y, op['alpha'])
+            elif t == ns.OP_MAXPOOL:
+                ho, wo, _ = spec.tensors[op['out']]
+                st = op['stride']
+                pb = max((ho - 1) * st + 2 - x.shape[2], 0)
+                pr = max((wo - 1) * st + 2 - x.shape[3], 0)
+                y = F.max_pool2d(F.pad(x, (0, pr, 0, pb), value=float('-inf')), 2, st)
+            elif t == ns.OP_UPSAMPLE:
+                y = F.interpolate(x, scale_factor=2, mode='nearest')
+            elif t == ns.OP_CONCAT:
+                y = torch.cat([x, T[op['in1']]], 1)
+            elif t == ns.OP_ADD:
+                y = x + T[op['in1']]
+            else:
+                raise ValueError(t)
+            T[op['out']] = y
+    return {i: T[i].permute(0, 2, 3, 1).float().numpy() for i in want}
