@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py — images/sec end-to-end, yolo_mobilev1-0.75, 224x320 network tensor (320x240 frames), B=32/GPU.
+
+One "step" = one pass of the hot path over one batch of synthetic u8 frames ALREADY RESIDENT IN HBM:
+  per-image max normalise -> conv backbone + head (HIP, fp16 storage / fp32 accumulate) ->
+  Python-mode decode + per-class NMS (keras_inference.py:94-135 semantics) -> detections in HBM.
+N>1: one process per GPU (torch.distributed / RCCL used only for the barrier + max-over-ranks of the
+timing); images are sharded across ranks, weights replicated, NO data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (HIP-event timing on the launch stream) and `cpu_baseline` (the CPU oracle, kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+
+
+def cpu_baseline(spec, weights, anchors, budget_s=12.0):
+    """The oracle (port of the reference's CPU path: normalise -> conv stack fp32 -> decode+NMS), timed on the
+    host cores on a bounded sample of the same workload."""
+    import oracle
+    from oracle import decode_ref
+    plan = spec.compile_plan(weights)
+    rng = np.random.default_rng(0)
+    nimg, t_total, n = 4, 0.0, 0
+    cores = os.cpu_count() or 1
+    while t_total < budget_s and n < 64:
+        frames = rng.integers(0, 256, (nimg, *spec.in_hw, 3), dtype=np.uint8)
+        t0 = time.perf_counter()
+        x = oracle.normalise_u8(frames)
+        outs = oracle.net_forward(plan, x, emulate_f16=False, out_ids=spec.outputs)
+        decode_ref.decode_batch([o.reshape(nimg, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors,
+                                spec.in_hw, spec.in_hw, 0.7, 0.5)
+        t_total += time.perf_counter() - t0
+        n += nimg
+    return {'value': round(n / t_total, 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} synthetic 224x320 frames through oracle/yolo_net_ref.c (fp32, OpenMP {cores} threads) + '
+                      f'oracle/decode_ref.py, {t_total:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE: 32)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from k210_yolo_framework_amd import engine, netspec
+    from k210_yolo_framework_amd.helper import VOC_ANCHORS
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    engine.require_gpu()
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+
+    spec = netspec.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    weights = spec.init_weights(seed=1)
+    B = args.batch
+    plan = engine.Plan(spec, weights, max_batch=B, device=local)
+    cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
+    g = torch.Generator(device='cuda').manual_seed(rank)
+    frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
+    outs = plan.outputs()
+
+    def step():
+        plan.run_u8(frames)
+        return engine.decode_py(cfg, outs, B, None, 0.7, 0.5)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets, counts = step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, HIP events on the launch stream
+        ms = plan.profile(frames, iters=20)
+        launches = plan.launches()
+        dom = int(np.argmax(ms))
+        name, flops_img, bytes_img = launches[dom]
+        alg_bytes = bytes_img * B
+        alg_flops = flops_img * B
+        t_dom = float(ms[dom]) * 1e-3
+        hbm_bound = (alg_bytes / (HBM_PEAK_GBS * 1e9)) >= (alg_flops / (MFMA_PEAK_TFLOPS * 1e12))
+        if hbm_bound:
+            ach = alg_bytes / t_dom / 1e9
+            roof = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None}
+        else:
+            ach = alg_flops / t_dom / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None}
+        roof.update({'kernel': name, 'avg_us': round(float(ms[dom]) * 1e3, 2),
+                     'sum_kernels_us': round(float(ms.sum()) * 1e3, 1),
+                     'per_kernel_us': {f'{i}:{launches[i][0]}': round(float(ms[i]) * 1e3, 2) for i in range(len(ms))}})
+        tot_bytes = sum(l[2] for l in launches) * B
+        tot_flops = sum(l[1] for l in launches) * B
+        out = {
+            'metric': 'images/sec end-to-end, yolo_mobilev1-0.75 320x240 b32',
+            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16 storage / f32 accumulate', 'data': 'synthetic u8 frames resident in HBM, seeded random-init weights',
+            'config': {'workload': 'configs[1]: yolo_mobilev1 alpha=0.75, network tensor 224x320x3 (320x240 frame, SURVEY F1), '
+                                   '20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
+                       'algorithmic_GB_per_step': round(tot_bytes / 1e9, 4), 'algorithmic_GFLOP_per_step': round(tot_flops / 1e9, 2),
+                       'parallelism': f'image-sharded x{world}, no collective'},
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(spec, weights, VOC_ANCHORS)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

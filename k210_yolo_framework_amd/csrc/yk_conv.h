@@ -14,6 +14,25 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 static inline int yk_pad8(int c) { return (c + 7) & ~7; }
 
+// unsigned division by a launch-invariant divisor without the ~40-instruction software divide:
+// q = (umulhi(n, mul) + n) >> shift, exact for n < 2^31 (Granlund-Montgomery round-up method)
+struct yk_fastdiv {
+    uint32_t mul, shift;
+};
+static inline yk_fastdiv yk_make_fastdiv(uint32_t d) {
+    yk_fastdiv f;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+// activation as y = min(max(v, v*slope), cap): relu slope 0, leaky slope alpha, none slope 1; relu6 cap 6
+static inline void yk_act_params(int act, float alpha, float *slope, float *cap) {
+    *slope = (act == YK_ACT_NONE) ? 1.f : (act == YK_ACT_LEAKY ? alpha : 0.f);
+    *cap = (act == YK_ACT_RELU6) ? 6.f : __builtin_huge_valf();
+}
+
 // ---- implicit-GEMM conv (1x1 / 3x3, stride 1/2, optional [up2(src0), src1] concat input) -------
 struct igemm_args {
     const yk_half *in0, *in1;   // in1 may be null
@@ -27,6 +46,11 @@ struct igemm_args {
     const float *scale, *bias;  // [N]
     int act;
     float alpha;
+    float slope, cap;           // yk_act_params(act, alpha)
+    yk_fastdiv fd_hw, fd_wo;    // division by Ho*Wo and Wo
+    int split_k;                // >1: partial sums go to `slab` [split][M][ldn] fp32, finished by yk_launch_splitk_reduce
+    float *slab;
+    int ldn;
     const yk_half *res;         // residual added after the activation (pitch resp), or null
     int resp;
     void *out;                  // fp16 pitch outp, or fp32 pitch outp when out_f32
@@ -35,11 +59,15 @@ struct igemm_args {
     const yk_half *dw_w;        // [9][c0p] fp16 or null
     const float *dw_scale, *dw_bias;
     int dw_act, dw_stride, dw_pad_t, dw_pad_l, dw_Hi, dw_Wi;
+    float dw_slope, dw_cap;
 };
-enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_128x80,
+enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_64x80,
        IGEMM_F32_128x64, IGEMM_NUM };
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st);
 int yk_igemm_pick(const igemm_args &a, bool out_f32);
+// split-K policy for a picked config (1 = no split) and the finishing pass
+int yk_igemm_split(int cfg, const igemm_args &a);
+int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st);
 const char *yk_igemm_name(int cfg);
 
 // fused DepthwiseConv2D(3x3)+BN+act -> Conv2D(1x1)+BN+act: the depthwise tile is produced straight
@@ -60,6 +88,7 @@ struct first_args {
     const float *scale, *bias;
     int act;
     float alpha;
+    float slope, cap;
     yk_half *out;
 };
 int yk_launch_first(const first_args &a, hipStream_t st);
@@ -73,6 +102,7 @@ struct dw_args {
     const float *scale, *bias;  // [Cp] (pad lanes: scale 0, bias 0)
     int act;
     float alpha;
+    float slope, cap;
     yk_half *out;
 };
 int yk_launch_dw(const dw_args &a, hipStream_t st);

@@ -1,73 +1,95 @@
 // yk_conv.hip — gfx950 kernels of the conv stack (models/yolonet.py, keras_mobilenet*.py layers).
 //
-//  igemm_kernel   Conv2D 1x1 / 3x3 (stride 1|2, explicit top/left pad) as an implicit GEMM on
-//                 v_mfma_f32_16x16x32_f16; optional virtual input = Concatenate([UpSampling2D(2)(a), b]);
-//                 epilogue = folded BatchNorm (fp32 scale/bias) + LeakyReLU/ReLU/ReLU6 (+ residual Add),
-//                 staged through LDS so global stores are 16 B per lane and row-contiguous.
-//                 Operands are swapped (A := weights, B := pixels) so that each lane's four
-//                 accumulator registers are four CONSECUTIVE output channels of one pixel.
-//  first_conv     the 3-channel stem conv, reading u8 frames with Helper._process_img's
-//                 `img / np.max(img)` fused in (per-image LUT), or fp32 input.
-//  dw_kernel      DepthwiseConv2D 3x3, NHWC, 8 channels (16 B) per lane.
-//  pool_kernel    MaxPooling2D 2x2 'same' (stride 2 and the stride-1 case of tiny_yolo).
-//  u8_max_kernel  per-image max for the normalisation.
+//  igemm_kernel     Conv2D 1x1 / 3x3 (stride 1|2, explicit top/left pad) as an implicit GEMM on
+//                   v_mfma_f32_16x16x32_f16; optional virtual input = Concatenate([UpSampling2D(2)(a), b]);
+//                   epilogue = folded BatchNorm (fp32 scale/bias) + LeakyReLU/ReLU/ReLU6 (+ residual Add),
+//                   staged through LDS so global stores are 16 B per lane and row-contiguous.
+//                   Operands are swapped (A := weights, B := pixels) so that each lane's four
+//                   accumulator registers are four CONSECUTIVE output channels of one pixel.
+//                   Small-M / large-K layers (the 7x10 and 14x20 head convs at batch 32) run split-K:
+//                   partial fp32 slabs + a deterministic finishing pass (splitk_reduce_kernel).
+//  fused_dwpw       DepthwiseConv2D 3x3 + BN + ReLU -> Conv2D 1x1 + BN + LeakyReLU in one launch.
+//  first_conv       the 3-channel stem conv, reading u8 frames with Helper._process_img's
+//                   `img / np.max(img)` fused in (per-image LUT), or fp32 input.
+//  dw_kernel        standalone DepthwiseConv2D 3x3, NHWC, 8 channels (16 B) per lane.
+//  pool_kernel      MaxPooling2D 2x2 'same' (stride 2 and the stride-1 case of tiny_yolo).
+//  u8_max_kernel    per-image max for the normalisation (one workgroup per image, no atomics).
 #include "yk_conv.h"
 
-__device__ __forceinline__ float yk_act(float v, int act, float alpha) {
-    switch (act) {
-    case YK_ACT_RELU: return v > 0.f ? v : 0.f;
-    case YK_ACT_RELU6: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
-    case YK_ACT_LEAKY: return v >= 0.f ? v : v * alpha;
-    default: return v;
-    }
+// y = min(max(v, v*slope), cap): branch-free LeakyReLU / ReLU / ReLU6 / identity (yk_act_params)
+__device__ __forceinline__ float yk_actf(float v, float slope, float cap) { return fminf(fmaxf(v, v * slope), cap); }
+
+__device__ __forceinline__ uint32_t yk_div(uint32_t n, yk_fastdiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
+
+// acc += f16(lo|hi half of a) * f16(lo|hi half of b): one VALU op, fp32 accumulate, no conversions
+__device__ __forceinline__ void fma_mix_lo(float &acc, uint32_t a, uint32_t b) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fma_mix_hi(float &acc, uint32_t a, uint32_t b) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// bijective XCD-aware remap of a 1-D tile index: consecutive tiles land on the same XCD (block b runs
+// on XCD b%8), so halo rows / weight panels shared by neighbouring tiles hit that XCD's L2.
+__device__ __forceinline__ int yk_xcd_tile(int bid, int nt) {
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // =====================================================================================
-// implicit GEMM
+// implicit GEMM.  OUT: 0 = fp16 through LDS, 1 = fp32 direct (network outputs), 2 = split-K slab
 // =====================================================================================
-template <int BM, int BN, int WM, int WN, bool OUT_F32>
+template <int BM, int BN, int WM, int WN, int BK, int OUT>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a) {
     constexpr int NT = 64 * WM * WN;
-    constexpr int BK = 32, LD = 40;                 // 80-byte LDS rows: 16 B aligned, spreads banks
+    constexpr int LD = BK + 8;                      // LDS row pitch (halfs): 16 B aligned, spreads banks
+    constexpr int CPR = BK / 8;                     // 16-byte chunks per tile row
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int A_VEC = BM * 4, B_VEC = BN * 4;   // 16-byte vectors per tile
+    constexpr int A_VEC = BM * CPR, B_VEC = BN * CPR;
     constexpr int A_IT = (A_VEC + NT - 1) / NT, B_IT = (B_VEC + NT - 1) / NT;
     constexpr int STAGE = (BM + BN) * LD;
     constexpr int CS_LD = BN + 8;
-    constexpr int CS_HALFS = OUT_F32 ? 0 : BM * CS_LD;
+    constexpr int CS_HALFS = (OUT == 0) ? BM * CS_LD : 0;
     constexpr int LDS_HALFS = (2 * STAGE > CS_HALFS) ? 2 * STAGE : CS_HALFS;
     __shared__ __attribute__((aligned(16))) yk_half lds[LDS_HALFS];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kc = tid & 3;                         // this thread's 8-wide k chunk inside a BK step
+    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    const int kc = tid % CPR;                       // this thread's 8-wide k chunk inside a BK step
     const int Ctp = a.c0p + a.c1p;
     const int taps = a.ks * a.ks;
     const int H0 = a.up0 ? (a.Hi >> 1) : a.Hi, W0 = a.up0 ? (a.Wi >> 1) : a.Wi;
+
+    // K range of this split
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int per = (nk_all + a.split_k - 1) / a.split_k;
+    const int kt0 = blockIdx.z * per;
+    const int nk = min(per, nk_all - kt0);
 
     // ---- per-thread A rows (fixed over the K loop)
     int rb[A_IT], riy[A_IT], rix[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int v = tid + it * NT, row = v >> 2, m = m0 + row;
+        const int v = tid + it * NT, row = v / CPR, m = m0 + row;
         if (v < A_VEC && m < a.M) {
-            const int hw = a.Ho * a.Wo;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const uint32_t b = yk_div(m, a.fd_hw), rem = m - b * (a.Ho * a.Wo);
+            const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
             rb[it] = b;
-            riy[it] = oy * a.stride - a.pad_t;
-            rix[it] = ox * a.stride - a.pad_l;
+            riy[it] = (int)oy * a.stride - a.pad_t;
+            rix[it] = (int)ox * a.stride - a.pad_l;
         } else {
             rb[it] = 0;
             riy[it] = -(1 << 28);
             rix[it] = 0;
         }
     }
-    int kch = kc * 8, ktap = 0;                     // (channel-in-tap, tap) of this thread's chunk
-    while (kch >= Ctp) {
-        kch -= Ctp;
-        ++ktap;
+    int kch = kt0 * BK + kc * 8, ktap = 0;          // (channel-in-tap, tap) of this thread's chunk
+    if (kch >= Ctp) {
+        ktap = kch / Ctp;
+        kch -= ktap * Ctp;
     }
 
     half8 ra[A_IT], rbv[B_IT];
@@ -92,7 +114,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int vv = tid + it * NT, row = vv >> 2, n = n0 + row, k = k0 + kc * 8;
+            const int vv = tid + it * NT, row = vv / CPR, n = n0 + row, k = k0 + kc * 8;
             if (vv < B_VEC && n < a.N && k < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + k);
             rbv[it] = v;
         }
@@ -107,12 +129,12 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int v = tid + it * NT;
-            if (v < A_VEC) *reinterpret_cast<half8 *>(As + (v >> 2) * LD + kc * 8) = ra[it];
+            if (v < A_VEC) *reinterpret_cast<half8 *>(As + (v / CPR) * LD + kc * 8) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int v = tid + it * NT;
-            if (v < B_VEC) *reinterpret_cast<half8 *>(Bs + (v >> 2) * LD + kc * 8) = rbv[it];
+            if (v < B_VEC) *reinterpret_cast<half8 *>(Bs + (v / CPR) * LD + kc * 8) = rbv[it];
         }
     };
 
@@ -122,109 +144,186 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (a.K + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    int cur = 0;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        const yk_half *As = lds + cur * STAGE, *Bs = As + BM * LD;
-        half8 wf[TN], xf[TM];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * LD + fk);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LD + fk);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) sstore(cur ^ 1);
+    if (nk > 0) {
+        gload(kt0 * BK);
+        sstore(0);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) gload((kt0 + kt + 1) * BK);
+            const yk_half *As = lds + cur * STAGE, *Bs = As + BM * LD;
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                half8 wf[TN], xf[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * LD + ks * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LD + ks * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) sstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue: lane holds channels n..n+3 (acc regs) of pixel m = lane&15
     const int nl4 = (lane >> 4) * 4;
+    if constexpr (OUT == 2) {
+        float *slab = a.slab + (size_t)blockIdx.z * a.M * a.ldn;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 16 + nl4;
+                if (m < a.M && n < a.ldn)
+                    *reinterpret_cast<float4 *>(slab + (size_t)m * a.ldn + n) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    } else {
+        float4 sc[TN], bs[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nl = (wn * TN + j) * 16 + nl4, n = n0 + nl;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n);   // arrays padded past N with zeros
-            const float4 bs = *reinterpret_cast<const float4 *>(a.bias + n);
-            float v0 = yk_act(acc[i][j][0] * sc.x + bs.x, a.act, a.alpha);
-            float v1 = yk_act(acc[i][j][1] * sc.y + bs.y, a.act, a.alpha);
-            float v2 = yk_act(acc[i][j][2] * sc.z + bs.z, a.act, a.alpha);
-            float v3 = yk_act(acc[i][j][3] * sc.w + bs.w, a.act, a.alpha);
-            if constexpr (OUT_F32) {
-                if (m < a.M) {
-                    float *o = reinterpret_cast<float *>(a.out) + (size_t)m * a.outp + n;
-                    if (n + 0 < a.N) o[0] = v0;
-                    if (n + 1 < a.N) o[1] = v1;
-                    if (n + 2 < a.N) o[2] = v2;
-                    if (n + 3 < a.N) o[3] = v3;
+            const int n = n0 + (wn * TN + j) * 16 + nl4;
+            sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);   // arrays padded past N with zeros
+            bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 16 + nl4, n = n0 + nl;
+                const float v0 = yk_actf(acc[i][j][0] * sc[j].x + bs[j].x, a.slope, a.cap);
+                const float v1 = yk_actf(acc[i][j][1] * sc[j].y + bs[j].y, a.slope, a.cap);
+                const float v2 = yk_actf(acc[i][j][2] * sc[j].z + bs[j].z, a.slope, a.cap);
+                const float v3 = yk_actf(acc[i][j][3] * sc[j].w + bs[j].w, a.slope, a.cap);
+                if constexpr (OUT == 1) {
+                    if (m < a.M) {
+                        float *o = reinterpret_cast<float *>(a.out) + (size_t)m * a.outp + n;
+                        if (n + 0 < a.N) o[0] = v0;
+                        if (n + 1 < a.N) o[1] = v1;
+                        if (n + 2 < a.N) o[2] = v2;
+                        if (n + 3 < a.N) o[3] = v3;
+                    }
+                } else {
+                    half4 h = {(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
+                    if (a.res && m < a.M && n < a.resp) {
+                        // Add(inputs, x): the conv result is first rounded to its fp16 storage value
+                        const half4 r = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
+                        h = half4{(yk_half)((float)h[0] + (float)r[0]), (yk_half)((float)h[1] + (float)r[1]),
+                                  (yk_half)((float)h[2] + (float)r[2]), (yk_half)((float)h[3] + (float)r[3])};
+                    }
+                    *reinterpret_cast<half4 *>(lds + ml * CS_LD + nl) = h;
                 }
-            } else {
-                half4 h = {(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
-                if (a.res && m < a.M && n < a.resp) {
-                    // Add(inputs, x): the conv result is first rounded to its fp16 storage value
-                    const half4 r = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
-                    h = half4{(yk_half)((float)h[0] + (float)r[0]), (yk_half)((float)h[1] + (float)r[1]),
-                              (yk_half)((float)h[2] + (float)r[2]), (yk_half)((float)h[3] + (float)r[3])};
-                }
-                *reinterpret_cast<half4 *>(lds + ml * CS_LD + nl) = h;
+            }
+        }
+        if constexpr (OUT == 0) {
+            __syncthreads();
+            constexpr int VPR = BN / 8;
+            yk_half *o = reinterpret_cast<yk_half *>(a.out);
+            for (int v = tid; v < BM * VPR; v += NT) {
+                const int row = v / VPR, cv = v - row * VPR, m = m0 + row, col = n0 + cv * 8;
+                if (m < a.M && col < a.outp)
+                    *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) =
+                        *reinterpret_cast<const half8 *>(lds + row * CS_LD + cv * 8);
             }
         }
     }
-    if constexpr (!OUT_F32) {
-        __syncthreads();
-        constexpr int VPR = BN / 8;
-        yk_half *o = reinterpret_cast<yk_half *>(a.out);
-        for (int v = tid; v < BM * VPR; v += NT) {
-            const int row = v / VPR, cv = v - row * VPR, m = m0 + row, col = n0 + cv * 8;
-            if (m < a.M && col < a.outp)
-                *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) =
-                    *reinterpret_cast<const half8 *>(lds + row * CS_LD + cv * 8);
+}
+
+// finishing pass of split-K: sum the slabs in a fixed order (deterministic), then the conv epilogue
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const igemm_args a) {
+    const int n4 = a.ldn >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (size_t)m * n4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *p = a.slab + (size_t)m * a.ldn + n;
+    const size_t zs = (size_t)a.M * a.ldn;
+    for (int z = 0; z < a.split_k; ++z) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + z * zs);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
+    const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n), bs = *reinterpret_cast<const float4 *>(a.bias + n);
+    const float v0 = yk_actf(s.x * sc.x + bs.x, a.slope, a.cap), v1 = yk_actf(s.y * sc.y + bs.y, a.slope, a.cap);
+    const float v2 = yk_actf(s.z * sc.z + bs.z, a.slope, a.cap), v3 = yk_actf(s.w * sc.w + bs.w, a.slope, a.cap);
+    if constexpr (OUT_F32) {
+        float *o = reinterpret_cast<float *>(a.out) + (size_t)m * a.outp + n;
+        if (n + 0 < a.N) o[0] = v0;
+        if (n + 1 < a.N) o[1] = v1;
+        if (n + 2 < a.N) o[2] = v2;
+        if (n + 3 < a.N) o[3] = v3;
+    } else {
+        if (n >= a.outp) return;
+        half4 h = {(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
+        if (a.res && n < a.resp) {
+            const half4 r = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
+            h = half4{(yk_half)((float)h[0] + (float)r[0]), (yk_half)((float)h[1] + (float)r[1]),
+                      (yk_half)((float)h[2] + (float)r[2]), (yk_half)((float)h[3] + (float)r[3])};
         }
+        *reinterpret_cast<half4 *>(reinterpret_cast<yk_half *>(a.out) + (size_t)m * a.outp + n) = h;
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool F32>
-static int launch_cfg(const igemm_args &a, hipStream_t st) {
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, F32>), grid, dim3(64 * WM * WN), 0, st, a);
+int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
+    const size_t total = (size_t)a.M * (a.ldn >> 2);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (out_f32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, dim3(256), 0, st, a);
     return YK_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int BK, bool F32>
+static int launch_cfg(const igemm_args &a, hipStream_t st) {
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
+    if (a.split_k > 1) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, 2>), grid, dim3(64 * WM * WN), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, F32 ? 1 : 0>), grid, dim3(64 * WM * WN), 0, st, a);
+    return YK_OK;
+}
+
+struct igemm_cfg_info {
+    int bm, bn, bk;
+    const char *name;
+};
+static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
+    {128, 64, 32, "igemm_128x64"}, {128, 48, 32, "igemm_128x48"}, {128, 96, 32, "igemm_128x96"},
+    {128, 192, 32, "igemm_128x192"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 32, "igemm_128x128"},
+    {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}};
+
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
-    case IGEMM_128x64: return launch_cfg<128, 64, 2, 2, false>(a, st);
-    case IGEMM_128x48: return launch_cfg<128, 48, 4, 1, false>(a, st);
-    case IGEMM_128x96: return launch_cfg<128, 96, 4, 1, false>(a, st);
-    case IGEMM_128x192: return launch_cfg<128, 192, 4, 1, false>(a, st);
-    case IGEMM_64x64: return launch_cfg<64, 64, 2, 2, false>(a, st);
-    case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, false>(a, st);
-    case IGEMM_F32_128x80: return launch_cfg<128, 80, 4, 1, true>(a, st);
-    case IGEMM_F32_128x64: return launch_cfg<128, 64, 2, 2, true>(a, st);
+    case IGEMM_128x64: return launch_cfg<128, 64, 2, 2, 32, false>(a, st);
+    case IGEMM_128x48: return launch_cfg<128, 48, 4, 1, 32, false>(a, st);
+    case IGEMM_128x96: return launch_cfg<128, 96, 4, 1, 32, false>(a, st);
+    case IGEMM_128x192: return launch_cfg<128, 192, 4, 1, 32, false>(a, st);
+    case IGEMM_64x64: return launch_cfg<64, 64, 2, 2, 64, false>(a, st);
+    case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, 32, false>(a, st);
+    case IGEMM_F32_64x80: return launch_cfg<64, 80, 4, 1, 64, true>(a, st);
+    case IGEMM_F32_128x64: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
     }
     yk_set_error("yk_launch_igemm: bad config %d", cfg);
     return YK_ERR_ARG;
 }
 
-const char *yk_igemm_name(int cfg) {
-    static const char *n[] = {"igemm_128x64", "igemm_128x48", "igemm_128x96", "igemm_128x192", "igemm_64x64",
-                              "igemm_128x128", "igemm_f32_128x80", "igemm_f32_128x64"};
-    return (cfg >= 0 && cfg < IGEMM_NUM) ? n[cfg] : "?";
-}
+const char *yk_igemm_name(int cfg) { return (cfg >= 0 && cfg < IGEMM_NUM) ? g_cfg[cfg].name : "?"; }
 
 int yk_igemm_pick(const igemm_args &a, bool out_f32) {
-    if (out_f32) return a.N <= 80 ? IGEMM_F32_128x80 : IGEMM_F32_128x64;
+    if (out_f32) return a.N <= 80 ? IGEMM_F32_64x80 : IGEMM_F32_128x64;
     const long mt128 = (a.M + 127) / 128;
     if (a.N == 48) return IGEMM_128x48;
     if (a.N == 96) return IGEMM_128x96;
@@ -232,6 +331,18 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     if (a.N >= 128 && mt128 * ((a.N + 127) / 128) >= 512) return IGEMM_128x128;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;
+}
+
+// split K when the (M,N) tiling alone cannot fill 256 CUs and K is long enough to share out
+int yk_igemm_split(int cfg, const igemm_args &a) {
+    const igemm_cfg_info &c = g_cfg[cfg];
+    const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+    const int nk = (a.K + c.bk - 1) / c.bk;
+    if (tiles >= 384 || nk < 6) return 1;
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > nk / 3) s = nk / 3;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
 }
 
 // =====================================================================================
@@ -291,7 +402,7 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const first_args a) {
     for (int c8 = 0; c8 < COUT; c8 += 8) {
         half8 h;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (yk_half)yk_act(acc[c8 + j] * sc[c8 + j] + bs[c8 + j], a.act, a.alpha);
+        for (int j = 0; j < 8; ++j) h[j] = (yk_half)yk_actf(acc[c8 + j] * sc[c8 + j] + bs[c8 + j], a.slope, a.cap);
         *reinterpret_cast<half8 *>(o + c8) = h;
     }
 }
@@ -307,44 +418,47 @@ int yk_launch_first(const first_args &a, hipStream_t st) {
     return YK_OK;
 }
 
-// per-image max of u8 frames -> img_max[b] (must be zeroed before the launch)
-__global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__ f, size_t per_image, int vec_ok,
-                                                     unsigned *__restrict__ img_max) {
-    const int b = blockIdx.y;
+// per-image max of u8 frames -> img_max[b]; one 1024-thread workgroup per image, plain store
+__global__ void __launch_bounds__(1024) u8_max_kernel(const uint8_t *__restrict__ f, size_t per_image, int vec_ok,
+                                                      unsigned *__restrict__ img_max) {
+    __shared__ unsigned part[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const uint8_t *p = f + (size_t)b * per_image;
     unsigned m = 0;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
     if (vec_ok) {
         const uint4 *q = reinterpret_cast<const uint4 *>(p);
         const size_t n16 = per_image / 16;
-        for (size_t i = t; i < n16; i += nth) {
+        for (size_t i = tid; i < n16; i += 1024) {
             const uint4 v = q[i];
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
                 m = max(m, max(max(w[j] & 0xffu, (w[j] >> 8) & 0xffu), max((w[j] >> 16) & 0xffu, w[j] >> 24)));
-            }
         }
-        for (size_t i = n16 * 16 + t; i < per_image; i += nth) m = max(m, (unsigned)p[i]);
+        for (size_t i = n16 * 16 + tid; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
     } else {
-        for (size_t i = t; i < per_image; i += nth) m = max(m, (unsigned)p[i]);
+        for (size_t i = tid; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(img_max + b, m);
+    if ((tid & 63) == 0) part[tid >> 6] = m;
+    __syncthreads();
+    if (tid < 16) {
+        m = part[tid];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if (tid == 0) img_max[b] = m;
+    }
 }
 
 int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st) {
     const int vec_ok = (per_image % 16 == 0) && ((uintptr_t)frames % 16 == 0);
-    int nblk = (int)((per_image / 16 + 255) / 256);
-    if (nblk < 1) nblk = 1;
-    if (nblk > 64) nblk = 64;
-    hipLaunchKernelGGL(u8_max_kernel, dim3(nblk, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
+    hipLaunchKernelGGL(u8_max_kernel, dim3(batch), dim3(1024), 0, st, frames, per_image, vec_ok, img_max);
     return YK_OK;
 }
 
 // =====================================================================================
-// depthwise 3x3
+// depthwise 3x3 (standalone)
 // =====================================================================================
 __global__ void __launch_bounds__(256) dw_kernel(const dw_args a) {
     const int G = a.Cp >> 3;
@@ -366,15 +480,18 @@ __global__ void __launch_bounds__(256) dw_kernel(const dw_args a) {
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ix0 + kx;
             if ((unsigned)ix >= (unsigned)a.Wi) continue;
-            const half8 x = *reinterpret_cast<const half8 *>(a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.Cp + g * 8);
-            const half8 w = *reinterpret_cast<const half8 *>(a.w + (size_t)(ky * 3 + kx) * a.Cp + g * 8);
+            const u32x4 x = *reinterpret_cast<const u32x4 *>(a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.Cp + g * 8);
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(a.w + (size_t)(ky * 3 + kx) * a.Cp + g * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)x[j] * (float)w[j];
+            for (int j = 0; j < 4; ++j) {
+                fma_mix_lo(acc[2 * j], x[j], w[j]);
+                fma_mix_hi(acc[2 * j + 1], x[j], w[j]);
+            }
         }
     }
     half8 h;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (yk_half)yk_act(acc[j] * a.scale[g * 8 + j] + a.bias[g * 8 + j], a.act, a.alpha);
+    for (int j = 0; j < 8; ++j) h[j] = (yk_half)yk_actf(acc[j] * a.scale[g * 8 + j] + a.bias[g * 8 + j], a.slope, a.cap);
     *reinterpret_cast<half8 *>(a.out + pix * a.Cp + g * 8) = h;
 }
 
@@ -443,12 +560,12 @@ int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, h
 // =====================================================================================
 // fused depthwise 3x3 -> pointwise 1x1  (MobileNet block: keras_mobilenet.py:359-436,
 // keras_mobilenet_v2.py:452-481).  One workgroup = BM consecutive output pixels x BN channels.
-//   phase A: depthwise + BN + act for the BM x Cin tile, fp32 math, rounded to fp16 into LDS
-//            (the stored value equals what the unfused pipeline would have written to HBM);
-//   phase B: [BN x K] (weights, streamed L2 -> registers, double-buffered) x [K x BM] (LDS) on
-//            v_mfma_f32_16x16x32_f16; epilogue as igemm_kernel.
-// blockIdx.x is remapped so that consecutive pixel tiles run on the same XCD (shared halo rows
-// stay in that XCD's L2).
+//   phase A: depthwise + BN + act for the BM x Cin tile: v_fma_mix_f32 (fp16 operands, fp32
+//            accumulate, no conversions), two pixels per thread in flight, result rounded to fp16
+//            into LDS (= what the unfused pipeline would have written to HBM);
+//   phase B: [BN x K] (weights, streamed L2 -> registers, WPF k-steps ahead, first ones issued
+//            BEFORE phase A so they overlap it) x [K x BM] (LDS) on v_mfma_f32_16x16x32_f16;
+//            epilogue as igemm_kernel.
 // =====================================================================================
 extern __shared__ __attribute__((aligned(16))) unsigned char yk_smem[];
 
@@ -457,16 +574,29 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int CS_LD = BN + 8;
+    constexpr int WPF = 2;                           // weight prefetch depth (k-steps of 32)
     yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int nk = Kp >> 5;
 
-    // XCD-aware (bijective) tile remap
-    const int nt = gridDim.x, bid = blockIdx.x;
-    const int q = nt >> 3, r = nt & 7, xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int m0 = tile * BM, n0 = blockIdx.y * BN;
+    // weight fragments: issue the first WPF k-steps now, they land while phase A runs
+    auto wload = [&](half8 (&wf)[TN], int k0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + fr, k = k0 + fk;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < a.N && k < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + k);
+            wf[j] = v;
+        }
+    };
+    half8 wq[WPF][TN];
+#pragma unroll
+    for (int s = 0; s < WPF; ++s)
+        if (s < nk) wload(wq[s], s * 32);
 
     // ---------------- phase A: depthwise producer ----------------
     {
@@ -474,42 +604,60 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
         const int PP = NT / G;                       // pixels per pass
         const int g = tid % G, pl = tid / G;
         if (pl < PP) {
-            half8 w[9];
+            u32x4 w[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)t * Cp + g * 8);
-            float sc[8], bs[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sc[j] = a.dw_scale[g * 8 + j];
-                bs[j] = a.dw_bias[g * 8 + j];
-            }
+            for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const u32x4 *>(a.dw_w + (size_t)t * Cp + g * 8);
+            const float4 sc0 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8);
+            const float4 sc1 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8 + 4);
+            const float4 bs0 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8);
+            const float4 bs1 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8 + 4);
             const int hw = a.Ho * a.Wo;
-            for (int p = pl; p < BM; p += PP) {
-                const int m = m0 + p;
-                half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < a.M) {
-                    const int b = m / hw, rem = m - b * hw;
-                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                    const int iy0 = oy * a.dw_stride - a.dw_pad_t, ix0 = ox * a.dw_stride - a.dw_pad_l;
-                    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const yk_half *inb = a.in0 + g * 8;
+            for (int p = pl; p < BM; p += 2 * PP) {
+                // two output pixels per iteration: 18 independent 16-byte loads in flight
+                u32x4 x[2][9];
+                bool live[2];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int iy = iy0 + ky;
-                        if ((unsigned)iy >= (unsigned)a.dw_Hi) continue;
+                for (int u = 0; u < 2; ++u) {
+                    const int pp = p + u * PP, m = m0 + pp;
+                    live[u] = (pp < BM);
+                    const bool valid = live[u] && m < a.M;
+                    const uint32_t b = yk_div(valid ? m : 0, a.fd_hw), rem = (valid ? m : 0) - b * hw;
+                    const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+                    const int iy0 = (int)oy * a.dw_stride - a.dw_pad_t, ix0 = (int)ox * a.dw_stride - a.dw_pad_l;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const int ix = ix0 + kx;
-                            if ((unsigned)ix >= (unsigned)a.dw_Wi) continue;
-                            const half8 x = *reinterpret_cast<const half8 *>(
-                                a.in0 + ((size_t)(b * a.dw_Hi + iy) * a.dw_Wi + ix) * Cp + g * 8);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[j] += (float)x[j] * (float)w[ky * 3 + kx][j];
+                            const int iy = iy0 + ky, ix = ix0 + kx;
+                            u32x4 v = {0, 0, 0, 0};
+                            if (valid && (unsigned)iy < (unsigned)a.dw_Hi && (unsigned)ix < (unsigned)a.dw_Wi)
+                                v = *reinterpret_cast<const u32x4 *>(inb + ((size_t)(b * a.dw_Hi + iy) * a.dw_Wi + ix) * Cp);
+                            x[u][ky * 3 + kx] = v;
                         }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) h[j] = (yk_half)yk_act(acc[j] * sc[j] + bs[j], a.dw_act, 0.f);
                 }
-                *reinterpret_cast<half8 *>(As + p * LDA + g * 8) = h;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!live[u]) continue;
+                    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            fma_mix_lo(acc[2 * j], x[u][t][j], w[t][j]);
+                            fma_mix_hi(acc[2 * j + 1], x[u][t][j], w[t][j]);
+                        }
+                    half8 h;
+                    h[0] = (yk_half)yk_actf(acc[0] * sc0.x + bs0.x, a.dw_slope, a.dw_cap);
+                    h[1] = (yk_half)yk_actf(acc[1] * sc0.y + bs0.y, a.dw_slope, a.dw_cap);
+                    h[2] = (yk_half)yk_actf(acc[2] * sc0.z + bs0.z, a.dw_slope, a.dw_cap);
+                    h[3] = (yk_half)yk_actf(acc[3] * sc0.w + bs0.w, a.dw_slope, a.dw_cap);
+                    h[4] = (yk_half)yk_actf(acc[4] * sc1.x + bs1.x, a.dw_slope, a.dw_cap);
+                    h[5] = (yk_half)yk_actf(acc[5] * sc1.y + bs1.y, a.dw_slope, a.dw_cap);
+                    h[6] = (yk_half)yk_actf(acc[6] * sc1.z + bs1.z, a.dw_slope, a.dw_cap);
+                    h[7] = (yk_half)yk_actf(acc[7] * sc1.w + bs1.w, a.dw_slope, a.dw_cap);
+                    *reinterpret_cast<half8 *>(As + (p + u * PP) * LDA + g * 8) = h;
+                }
             }
         }
         // zero the K padding (Cp..Kp) once
@@ -527,49 +675,44 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fk = (lane >> 4) * 8;
-    const int nk = Kp >> 5;
-    auto wload = [&](half8 (&wf)[TN], int k0) {
+    for (int kt = 0; kt < nk; kt += WPF) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 16 + fr, k = k0 + fk;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n < a.N && k < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + k);
-            wf[j] = v;
+        for (int s = 0; s < WPF; ++s) {
+            if (kt + s < nk) {
+                half8 xf[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LDA + (kt + s) * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s][j], xf[i], acc[i][j], 0, 0, 0);
+                if (kt + s + WPF < nk) wload(wq[s], (kt + s + WPF) * 32);
+            }
         }
-    };
-    half8 wcur[TN], wnext[TN];
-    wload(wcur, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wload(wnext, (kt + 1) * 32);
-        half8 xf[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LDA + kt * 32 + fk);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[j], xf[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wcur[j] = wnext[j];
     }
     __syncthreads();   // everyone is done with the A tile; reuse LDS for the output tile
 
     yk_half *Cs = reinterpret_cast<yk_half *>(yk_smem);
     const int nl4 = (lane >> 4) * 4;
+    float4 sc[TN], bs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 16 + nl4;
+        sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
+        bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = (wn * TN + j) * 16 + nl4, n = n0 + nl;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n);
-            const float4 bs = *reinterpret_cast<const float4 *>(a.bias + n);
-            half4 h = {(yk_half)yk_act(acc[i][j][0] * sc.x + bs.x, a.act, a.alpha),
-                       (yk_half)yk_act(acc[i][j][1] * sc.y + bs.y, a.act, a.alpha),
-                       (yk_half)yk_act(acc[i][j][2] * sc.z + bs.z, a.act, a.alpha),
-                       (yk_half)yk_act(acc[i][j][3] * sc.w + bs.w, a.act, a.alpha)};
+            half4 h = {(yk_half)yk_actf(acc[i][j][0] * sc[j].x + bs[j].x, a.slope, a.cap),
+                       (yk_half)yk_actf(acc[i][j][1] * sc[j].y + bs[j].y, a.slope, a.cap),
+                       (yk_half)yk_actf(acc[i][j][2] * sc[j].z + bs[j].z, a.slope, a.cap),
+                       (yk_half)yk_actf(acc[i][j][3] * sc[j].w + bs[j].w, a.slope, a.cap)};
             if (a.res && m < a.M && n < a.resp) {
                 const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
                 h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),

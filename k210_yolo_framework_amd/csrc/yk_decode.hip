@@ -86,18 +86,26 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     int *og = sel_g + ((size_t)b * C + c) * max_out;
     float *os = sel_s + ((size_t)b * C + c) * max_out;
     int n = 0;
-    for (int base = 0; base < ntot; base += 64) {
-        int i = base + lane;
-        float s = (i < ntot) ? sc[i] : -INFINITY;
-        bool f = (i < ntot) && (s >= obj_thresh);                    // keras_inference.py:116 (>=)
-        unsigned long long m = __ballot(f);
-        int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (f && pos < YK_NMS_MAXC) {
-            L.s[pos] = s;
-            L.idx[pos] = i;
-            L.box[pos] = bx[i];
+    for (int base0 = 0; base0 < ntot; base0 += 64 * 8) {
+        float sv[8];                                                  // 8 independent loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base0 + u * 64 + lane;
+            sv[u] = (i < ntot) ? sc[i] : -INFINITY;
         }
-        n += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base0 + u * 64 + lane;
+            const bool f = (i < ntot) && (sv[u] >= obj_thresh);      // keras_inference.py:116 (>=)
+            const unsigned long long m = __ballot(f);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (f && pos < YK_NMS_MAXC) {
+                L.s[pos] = sv[u];
+                L.idx[pos] = i;
+                L.box[pos] = bx[i];
+            }
+            n += __popcll(m);
+        }
     }
     __syncthreads();
     int kept = 0;

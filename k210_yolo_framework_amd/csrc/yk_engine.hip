@@ -59,7 +59,7 @@ float h2f_bits(uint16_t h) {
     return f;
 }
 
-enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD };
+enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD, K_U8MAX };
 enum { T_REAL = 0, T_UP = 1, T_CAT = 2 };
 
 struct tinfo {
@@ -81,6 +81,7 @@ struct launch {
     yk_half *add_o = nullptr;
     size_t add_n8_per_image = 0;
     int Ho = 0, Wo = 0;
+    bool out_f32 = false;
     std::string name;
     double flops = 0, bytes = 0;
 };
@@ -94,6 +95,8 @@ struct yk_plan {
     std::vector<void *> allocs;
     std::vector<int> outputs;
     unsigned *d_imgmax = nullptr;
+    float *d_slab = nullptr;
+    size_t slab_bytes = 0;
     int in_h = 0, in_w = 0;
     int last_batch = 0;
 };
@@ -261,6 +264,13 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
     if (rc) return fail(rc);
 
     // pass 2: launches
+    {
+        launch l;
+        l.kind = K_U8MAX;   // only issued by yk_run_u8: Helper._process_img's np.max(img)
+        l.name = "u8_max";
+        l.bytes = (double)p->in_h * p->in_w * 3;
+        p->L.push_back(l);
+    }
     for (int i = 0; i < n_ops; ++i) {
         if (skip[i]) continue;
         const int32_t *o = ops + (size_t)i * YK_OP_FIELDS;
@@ -295,6 +305,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &f.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &f.bias))) return fail(rc);
             f.act = o[YK_F_ACT]; f.alpha = alpha; f.out = Y.d;
+            yk_act_params(f.act, f.alpha, &f.slope, &f.cap);
             if (Y.cp != co) {
                 yk_set_error("op %d: stem conv Cout must be a multiple of 8", i);
                 return fail(YK_ERR_UNSUPPORTED);
@@ -352,6 +363,10 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &g.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &g.bias))) return fail(rc);
             g.act = o[YK_F_ACT]; g.alpha = alpha;
+            yk_act_params(g.act, g.alpha, &g.slope, &g.cap);
+            g.fd_hw = yk_make_fastdiv((uint32_t)(Y.h * Y.w));
+            g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
+            g.split_k = 1;
             tinfo *dst = &Y;
             if (add_of[i] >= 0) {
                 const int32_t *q = ops + (size_t)add_of[i] * YK_OP_FIELDS;
@@ -383,14 +398,24 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
                 g.dw_act = dwo[YK_F_ACT]; g.dw_stride = dwo[YK_F_STRIDE];
                 g.dw_pad_t = dwo[YK_F_PAD_T]; g.dw_pad_l = dwo[YK_F_PAD_L];
                 g.dw_Hi = dwX->h; g.dw_Wi = dwX->w;
+                yk_act_params(g.dw_act, 0.f, &g.dw_slope, &g.dw_cap);
                 dw_flops = 2.0 * X.h * X.w * 9 * c0;
                 dw_bytes = ((double)dwX->h * dwX->w * c0 + (double)X.h * X.w * c0) * 2;
             }
             g.M = max_batch * Y.h * Y.w;   // for config choice; patched per run
             l.cfg = dwo ? yk_igemm_fused_pick(g) : yk_igemm_pick(g, f32);
+            l.out_f32 = f32;
+            if (!dwo && env_flag("YK_SPLITK", true)) {
+                g.split_k = yk_igemm_split(l.cfg, g);
+                if (g.split_k > 1) {
+                    g.ldn = (co + 15) & ~15;
+                    p->slab_bytes = std::max(p->slab_bytes, (size_t)g.split_k * g.M * g.ldn * sizeof(float));
+                }
+            }
             snprintf(nm, sizeof nm, "%sconv%dx%ds%d_%dto%d%s%s[%s]", dwo ? "dw3x3+" : "", ks, ks, g.stride, o[YK_F_CIN], co,
                      g.res ? "+add" : "", s1 ? "+upcat" : (up0 ? "+up" : ""),
                      dwo ? yk_igemm_fused_name(l.cfg) : yk_igemm_name(l.cfg));
+            if (g.split_k > 1) snprintf(nm + strlen(nm), sizeof nm - strlen(nm), "/splitk%d", g.split_k);
             l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)o[YK_F_CIN] * co + dw_flops;
             l.bytes = ((double)X.h * X.w * o[YK_F_CIN] + (double)Y.h * Y.w * co) * 2 + dw_bytes;
         } else if (ty == YK_OP_DWCONV) {
@@ -413,6 +438,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], c, &d.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], c, &d.bias))) return fail(rc);
             d.act = o[YK_F_ACT]; d.alpha = alpha; d.out = Y.d;
+            yk_act_params(d.act, d.alpha, &d.slope, &d.cap);
             snprintf(nm, sizeof nm, "dw3x3s%d_%d", d.stride, c);
             l.flops = 2.0 * Y.h * Y.w * 9 * c;
             l.bytes = ((double)X.h * X.w * c + (double)Y.h * Y.w * c) * 2;
@@ -445,6 +471,9 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
         l.name = nm;
         p->L.push_back(l);
     }
+    if (p->slab_bytes) {
+        if ((rc = dev_alloc(p, (void **)&p->d_slab, p->slab_bytes, true))) return fail(rc);
+    }
     for (int t : p->outputs)
         if (!p->T[t].d32) {
             yk_set_error("yk_plan_create: output tensor %d is not produced by a NET_OUTPUT conv", t);
@@ -455,20 +484,23 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
     return YK_OK;
 }
 
-static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *stream) {
+static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *stream, hipEvent_t *ev = nullptr) {
     if (!p || !d_in || batch <= 0 || batch > p->max_batch) {
         yk_set_error("yk_run: bad plan/input/batch (max_batch=%d)", p ? p->max_batch : 0);
         return YK_ERR_ARG;
     }
     YK_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    if (!in_f32) {
-        YK_HIP(hipMemsetAsync(p->d_imgmax, 0, sizeof(unsigned) * batch, st));
-        yk_launch_u8_max((const uint8_t *)d_in, (size_t)p->in_h * p->in_w * 3, batch, p->d_imgmax, st);
-    }
+    int li = 0;
     for (launch &l : p->L) {
         int rc = YK_OK;
+        if (ev) YK_HIP(hipEventRecord(ev[2 * li], st));
         switch (l.kind) {
+        case K_U8MAX:
+            if (!in_f32) {
+                rc = yk_launch_u8_max((const uint8_t *)d_in, (size_t)p->in_h * p->in_w * 3, batch, p->d_imgmax, st);
+            }
+            break;
         case K_FIRST: {
             first_args f = l.f;
             f.in = d_in; f.in_f32 = in_f32; f.img_max = p->d_imgmax; f.B = batch;
@@ -477,7 +509,9 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
         case K_IGEMM: {
             igemm_args g = l.g;
             g.M = batch * l.Ho * l.Wo;
+            g.slab = p->d_slab;
             rc = g.dw_w ? yk_launch_igemm_fused(l.cfg, g, st) : yk_launch_igemm(l.cfg, g, st);
+            if (!rc && g.split_k > 1) rc = yk_launch_splitk_reduce(g, l.out_f32, st);
         } break;
         case K_DW: {
             dw_args d = l.d;
@@ -492,10 +526,39 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
         case K_ADD: rc = yk_launch_add(l.add_a, l.add_b, l.add_o, l.add_n8_per_image * batch, st); break;
         }
         if (rc) return rc;
+        if (ev) YK_HIP(hipEventRecord(ev[2 * li + 1], st));
+        ++li;
     }
     YK_HIP(hipGetLastError());
     p->last_batch = batch;
     return YK_OK;
+}
+
+// Per-launch timing with HIP events recorded on the SAME stream the kernels run on.
+// ms_out[i] = average duration of launch i over `iters` replays (i < yk_plan_launch_count).
+extern "C" int yk_plan_profile(yk_plan_t *p, const uint8_t *d_frames, int batch, int iters, void *stream, float *ms_out) {
+    if (!p || !ms_out || iters <= 0) {
+        yk_set_error("yk_plan_profile: bad argument");
+        return YK_ERR_ARG;
+    }
+    const int n = (int)p->L.size();
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto &e : ev) YK_HIP(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    int rc = YK_OK;
+    for (int it = 0; it < iters && rc == YK_OK; ++it) {
+        rc = run_plan(p, d_frames, 0, batch, stream, ev.data());
+        if (rc) break;
+        YK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            YK_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < n; ++i) ms_out[i] = (float)(acc[i] / iters);
+    return rc;
 }
 
 extern "C" int yk_run_u8(yk_plan_t *p, const uint8_t *d_frames, int batch, void *stream) {

@@ -60,7 +60,7 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_decode_py', 'yk_region_batched',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched',
                    'region_layer_init'):
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
@@ -168,6 +168,14 @@ class Plan:
         _check(lib().yk_debug_read_tensor(self._h, C.c_int(tid), C.c_int(batch), out.ctypes.data_as(f32p),
                                           C.c_size_t(out.size)), 'yk_debug_read_tensor')
         return out
+
+    def profile(self, frames, iters: int = 10, stream=None) -> np.ndarray:
+        """Average per-launch duration (ms) measured with HIP events on the launch stream."""
+        n = lib().yk_plan_launch_count(self._h)
+        ms = np.zeros(n, np.float32)
+        _check(lib().yk_plan_profile(self._h, _ptr(frames), C.c_int(frames.shape[0]), C.c_int(iters), _stream(stream),
+                                     ms.ctypes.data_as(f32p)), 'yk_plan_profile')
+        return ms
 
     def launches(self):
         n = lib().yk_plan_launch_count(self._h)
