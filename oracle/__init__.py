@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         _LIB.rlref_iou.restype = C.c_float
         _LIB.rlref_draw.restype = C.c_int
         _LIB.yk_ref_forward.restype = C.c_int
+        _LIB.yk_ref_forward_ex.restype = C.c_int
         _LIB.yk_ref_f16_round.restype = C.c_float
         _LIB.yk_ref_f16_round.argtypes = [C.c_float]
     return _LIB
@@ -174,6 +175,31 @@ def net_forward(plan, x: np.ndarray, emulate_f16: bool = False, out_ids: Optiona
     if rc != 0:
         raise RuntimeError(f'yk_ref_forward -> {rc}')
     return (outs, dump) if dump_id >= 0 else outs
+
+
+def net_forward_ex(plan, inputs: dict, op_rows: Sequence[int], out_ids: Sequence[int], emulate_f16: bool = True):
+    """Run only the ops `op_rows` of the plan with the tensors in `inputs` ({tensor id: fp32 NHWC}) pre-filled.
+    Used for layer-at-a-time parity (the GPU's own layer inputs go in, its layer output is compared)."""
+    L = lib()
+    ops, tens, blob = plan
+    sub = np.ascontiguousarray(np.asarray(ops, np.int32)[list(op_rows)], np.int32)
+    tens = np.ascontiguousarray(tens, np.int32)
+    blob = np.ascontiguousarray(blob, np.float32)
+    ids = np.ascontiguousarray(list(inputs.keys()), np.int32)
+    arrs = [np.ascontiguousarray(inputs[int(i)], np.float32) for i in ids]
+    B = arrs[0].shape[0]
+    in_ptrs = (f32p * len(arrs))(*[_p(a, f32p) for a in arrs])
+    oid = np.ascontiguousarray(out_ids, np.int32)
+    outs = [np.empty((B, *tens[i, :3]), np.float32) for i in oid]
+    out_ptrs = (f32p * len(outs))(*[_p(o, f32p) for o in outs])
+    dummy = np.empty(1, np.float32)
+    rc = L.yk_ref_forward_ex(_p(sub, i32p), C.c_int(len(sub)), _p(tens, i32p), C.c_int(len(tens)), _p(blob, f32p),
+                             C.c_size_t(blob.size), C.c_int(len(arrs)), _p(ids, i32p), in_ptrs, C.c_int(B),
+                             C.c_int(1 if emulate_f16 else 0), _p(oid, i32p), C.c_int(len(outs)), out_ptrs, C.c_int(-1),
+                             _p(dummy, f32p))
+    if rc != 0:
+        raise RuntimeError(f'yk_ref_forward_ex -> {rc}')
+    return outs
 
 
 def normalise_u8(frames: np.ndarray) -> np.ndarray:

@@ -76,9 +76,9 @@ typedef struct {
 /* returns 0 ok, <0 on error.  input: fp32 [batch][H][W][3] already normalised.
  * out_ptrs[i]: caller buffer for tensor out_ids[i], fp32 [batch][h][w][c].
  * dump_id >= 0 additionally copies that tensor into dump (fp32 NHWC). */
-int yk_ref_forward(const int32_t *ops, int n_ops, const int32_t *tensors, int n_t, const float *blob_in,
-                   size_t blob_len, const float *input, int batch, int emulate_f16, const int32_t *out_ids,
-                   int n_out, float **out_ptrs, int dump_id, float *dump) {
+int yk_ref_forward_ex(const int32_t *ops, int n_ops, const int32_t *tensors, int n_t, const float *blob_in,
+                      size_t blob_len, int n_in, const int32_t *in_ids, const float *const *in_ptrs, int batch,
+                      int emulate_f16, const int32_t *out_ids, int n_out, float **out_ptrs, int dump_id, float *dump) {
     tens_t *T = (tens_t *)calloc((size_t)n_t, sizeof(tens_t));
     if (!T) return -1;
     for (int i = 0; i < n_t; ++i) {
@@ -100,9 +100,13 @@ int yk_ref_forward(const int32_t *ops, int n_ops, const int32_t *tensors, int n_
             }
         }
     }
-    size_t in_elems = (size_t)batch * T[0].h * T[0].w * T[0].c;
-    T[0].d = (float *)malloc(sizeof(float) * in_elems);
-    memcpy(T[0].d, input, sizeof(float) * in_elems);
+    /* pre-filled tensors: the network input (id 0) or, for layer-at-a-time checks, any set of tensors */
+    for (int i = 0; i < n_in; ++i) {
+        const int id = in_ids[i];
+        size_t in_elems = (size_t)batch * T[id].h * T[id].w * T[id].c;
+        T[id].d = (float *)malloc(sizeof(float) * in_elems);
+        memcpy(T[id].d, in_ptrs[i], sizeof(float) * in_elems);
+    }
 
     int rc = 0;
     for (int i = 0; i < n_ops && rc == 0; ++i) {
@@ -110,8 +114,10 @@ int yk_ref_forward(const int32_t *ops, int n_ops, const int32_t *tensors, int n_
         const tens_t *X = &T[o[F_IN0]];
         tens_t *Y = &T[o[F_OUT]];
         const int Hi = X->h, Wi = X->w, Ci = X->c, Ho = Y->h, Wo = Y->w, Co = Y->c;
+        if (!X->d || (o[F_IN1] >= 0 && !T[o[F_IN1]].d)) { rc = -4; break; }   /* input never produced */
+        free(Y->d);
         Y->d = (float *)malloc(sizeof(float) * (size_t)batch * Ho * Wo * Co);
-        if (!Y->d || !X->d) { rc = -2; break; }
+        if (!Y->d) { rc = -2; break; }
         const int net_out = o[F_FLAGS] & 1;
         const int round_out = emulate_f16 && !net_out;
         float alpha;
@@ -228,6 +234,15 @@ int yk_ref_forward(const int32_t *ops, int n_ops, const int32_t *tensors, int n_
     free(T);
     free(blob);
     return rc;
+}
+
+int yk_ref_forward(const int32_t *ops, int n_ops, const int32_t *tensors, int n_t, const float *blob_in,
+                   size_t blob_len, const float *input, int batch, int emulate_f16, const int32_t *out_ids,
+                   int n_out, float **out_ptrs, int dump_id, float *dump) {
+    const int32_t id0 = 0;
+    const float *p0 = input;
+    return yk_ref_forward_ex(ops, n_ops, tensors, n_t, blob_in, blob_len, 1, &id0, &p0, batch, emulate_f16, out_ids,
+                             n_out, out_ptrs, dump_id, dump);
 }
 
 /* Helper._process_img's normalisation (tools/utils.py:405): img / np.max(img), computed in
