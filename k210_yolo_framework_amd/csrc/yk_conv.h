@@ -48,6 +48,9 @@ struct igemm_args {
     float alpha;
     float slope, cap;           // yk_act_params(act, alpha)
     yk_fastdiv fd_hw, fd_wo;    // division by Ho*Wo and Wo
+    yk_fastdiv fd_g;            // division by c0p/8 (fused depthwise producer)
+    yk_fastdiv fd_vpr;          // division by outp/8 (flat tile store)
+    uint32_t in0_bytes;         // byte size of in0 (buffer-load bounds)
     int split_k;                // >1: partial sums go to `slab` [split][M][ldn] fp32, finished by yk_launch_splitk_reduce
     float *slab;
     int ldn;
@@ -60,6 +63,7 @@ struct igemm_args {
     const float *dw_scale, *dw_bias;
     int dw_act, dw_stride, dw_pad_t, dw_pad_l, dw_Hi, dw_Wi;
     float dw_slope, dw_cap;
+    long long *dbg;             // dev instrumentation: per-workgroup phase timestamps (null in production)
 };
 enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_64x80,
        IGEMM_F32_128x64, IGEMM_NUM };
@@ -72,7 +76,10 @@ const char *yk_igemm_name(int cfg);
 
 // fused DepthwiseConv2D(3x3)+BN+act -> Conv2D(1x1)+BN+act: the depthwise tile is produced straight
 // into LDS (never written to HBM) and consumed as the MFMA pixel operand; weights stream from L2.
-enum { FUSED_128x48 = 0, FUSED_128x96, FUSED_64x192, FUSED_32x192, FUSED_NUM };
+enum { FUSED_128x48 = 0, FUSED_128x96, FUSED_64x192, FUSED_32x192,
+       WIDE_4x3_T4, WIDE_2x6_T4, WIDE_2x6_T2, WIDE_1x12_T4, WIDE_1x12_T2, WIDE_1x12_T2_D12, LR_T1, LR_T2,
+       WAVE_T1_N3, WAVE_T2_N3, WAVE_T1_N6, WAVE_T2_N6, WAVE_T1_N12, WAVE_T2_N12,
+       WIDE_1x12_T3_D12, WIDE_1x12_T5_D12, WIDE_1x12_T5, WIDE_1x12_T9, FUSED_NUM };
 bool yk_igemm_fused_ok(int c0p, int cout);
 int yk_igemm_fused_pick(const igemm_args &a);
 const char *yk_igemm_fused_name(int cfg);

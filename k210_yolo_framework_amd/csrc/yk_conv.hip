@@ -14,6 +14,8 @@
 //  dw_kernel        standalone DepthwiseConv2D 3x3, NHWC, 8 channels (16 B) per lane.
 //  pool_kernel      MaxPooling2D 2x2 'same' (stride 2 and the stride-1 case of tiny_yolo).
 //  u8_max_kernel    per-image max for the normalisation (one workgroup per image, no atomics).
+#include <stdlib.h>
+
 #include "yk_conv.h"
 
 // y = min(max(v, v*slope), cap): branch-free LeakyReLU / ReLU / ReLU6 / identity (yk_act_params)
@@ -37,6 +39,65 @@ __device__ __forceinline__ int yk_xcd_tile(int bid, int nt) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- depthwise 3x3 work item = (output pixel, 8 channels) --------------------------------------
+// Taps are fetched with raw buffer loads: out-of-image taps get an offset >= the buffer size and the
+// hardware returns zeros (Keras zero padding) — no per-tap branches, one 32-bit add per tap.
+#define YK_OOB 0x40000000u
+__device__ __forceinline__ void dw_issue(const igemm_args &a, const __amdgpu_buffer_rsrc_t rs, uint32_t m, uint32_t coff,
+                                         u32x4 (&x)[9]) {
+    const uint32_t hw = a.Ho * a.Wo, px = a.c0p * 2u, rowb = a.dw_Wi * px;
+    const uint32_t b = yk_div(m, a.fd_hw), rem = m - b * hw;
+    const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+    const int iy0 = (int)oy * a.dw_stride - a.dw_pad_t, ix0 = (int)ox * a.dw_stride - a.dw_pad_l;
+    const uint32_t boff = b * (a.dw_Hi * rowb) + coff;
+    uint32_t ro[3], co[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ro[k] = ((unsigned)(iy0 + k) < (unsigned)a.dw_Hi) ? boff + (uint32_t)(iy0 + k) * rowb : YK_OOB;
+        co[k] = ((unsigned)(ix0 + k) < (unsigned)a.dw_Wi) ? (uint32_t)(ix0 + k) * px : YK_OOB;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) x[ky * 3 + kx] = __builtin_amdgcn_raw_buffer_load_b128(rs, ro[ky] + co[kx], 0, 0);
+}
+template <bool CAPPED>
+__device__ __forceinline__ float yk_act2(float v, float slope, float cap) {
+    v = fmaxf(v, v * slope);
+    return CAPPED ? fminf(v, cap) : v;
+}
+// wl: this octet's depthwise weights in LDS, tap stride Cp halfs
+template <bool CAPPED>
+__device__ __forceinline__ half8 dw_finish(const u32x4 (&x)[9], const yk_half *wl, int Cp, const float4 sc0, const float4 sc1,
+                                           const float4 bs0, const float4 bs1, float slope, float cap) {
+    float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(wl + (size_t)t * Cp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fma_mix_lo(d[2 * j], x[t][j], w[j]);
+            fma_mix_hi(d[2 * j + 1], x[t][j], w[j]);
+        }
+    }
+    half8 h;
+    h[0] = (yk_half)yk_act2<CAPPED>(d[0] * sc0.x + bs0.x, slope, cap);
+    h[1] = (yk_half)yk_act2<CAPPED>(d[1] * sc0.y + bs0.y, slope, cap);
+    h[2] = (yk_half)yk_act2<CAPPED>(d[2] * sc0.z + bs0.z, slope, cap);
+    h[3] = (yk_half)yk_act2<CAPPED>(d[3] * sc0.w + bs0.w, slope, cap);
+    h[4] = (yk_half)yk_act2<CAPPED>(d[4] * sc1.x + bs1.x, slope, cap);
+    h[5] = (yk_half)yk_act2<CAPPED>(d[5] * sc1.y + bs1.y, slope, cap);
+    h[6] = (yk_half)yk_act2<CAPPED>(d[6] * sc1.z + bs1.z, slope, cap);
+    h[7] = (yk_half)yk_act2<CAPPED>(d[7] * sc1.w + bs1.w, slope, cap);
+    return h;
+}
+// conv epilogue for 4 consecutive channels of one pixel -> packed fp16
+template <bool CAPPED>
+__device__ __forceinline__ half4 epi4(const floatx4 c, const float4 sc, const float4 bs, float slope, float cap) {
+    return half4{(yk_half)yk_act2<CAPPED>(c[0] * sc.x + bs.x, slope, cap), (yk_half)yk_act2<CAPPED>(c[1] * sc.y + bs.y, slope, cap),
+                 (yk_half)yk_act2<CAPPED>(c[2] * sc.z + bs.z, slope, cap), (yk_half)yk_act2<CAPPED>(c[3] * sc.w + bs.w, slope, cap)};
+}
 
 // =====================================================================================
 // implicit GEMM.  OUT: 0 = fp16 through LDS, 1 = fp32 direct (network outputs), 2 = split-K slab
@@ -569,7 +630,7 @@ int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, h
 // =====================================================================================
 extern __shared__ __attribute__((aligned(16))) unsigned char yk_smem[];
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int IT>
 __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_args a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -582,6 +643,9 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
     const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     const int nk = Kp >> 5;
+#define YK_STAMP(k)                                                                                  \
+    if (a.dbg && tid == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)wall_clock64();
+    YK_STAMP(0)
 
     // weight fragments: issue the first WPF k-steps now, they land while phase A runs
     auto wload = [&](half8 (&wf)[TN], int k0) {
@@ -598,6 +662,7 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
     for (int s = 0; s < WPF; ++s)
         if (s < nk) wload(wq[s], s * 32);
 
+    YK_STAMP(1)
     // ---------------- phase A: depthwise producer ----------------
     {
         const int G = Cp >> 3;
@@ -613,12 +678,12 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
             const float4 bs1 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8 + 4);
             const int hw = a.Ho * a.Wo;
             const yk_half *inb = a.in0 + g * 8;
-            for (int p = pl; p < BM; p += 2 * PP) {
-                // two output pixels per iteration: 18 independent 16-byte loads in flight
-                u32x4 x[2][9];
-                bool live[2];
+            for (int p = pl; p < BM; p += IT * PP) {
+                // IT output pixels per iteration: 9*IT independent 16-byte loads in flight
+                u32x4 x[IT][9];
+                bool live[IT];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < IT; ++u) {
                     const int pp = p + u * PP, m = m0 + pp;
                     live[u] = (pp < BM);
                     const bool valid = live[u] && m < a.M;
@@ -637,7 +702,7 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
                         }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < IT; ++u) {
                     if (!live[u]) continue;
                     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -667,7 +732,9 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
             *reinterpret_cast<half8 *>(As + p * LDA + Cp + c * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    YK_STAMP(2)
     __syncthreads();
+    YK_STAMP(3)
 
     // ---------------- phase B: GEMM, weights streamed from L2 ----------------
     floatx4 acc[TM][TN];
@@ -692,7 +759,9 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
             }
         }
     }
+    YK_STAMP(4)
     __syncthreads();   // everyone is done with the A tile; reuse LDS for the output tile
+    YK_STAMP(5)
 
     yk_half *Cs = reinterpret_cast<yk_half *>(yk_smem);
     const int nl4 = (lane >> 4) * 4;
@@ -729,21 +798,448 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
         if (m < a.M && col < a.outp)
             *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) = *reinterpret_cast<const half8 *>(Cs + row * CS_LD + cv * 8);
     }
+    YK_STAMP(6)
+    if (a.dbg && tid == 0)
+        a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+            ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#undef YK_STAMP
 }
 
-template <int BM, int BN, int WM, int WN>
+
+// -------------------------------------------------------------------------------------
+// "wide" variant: 12 wavefronts (768 threads) per workgroup.  Built for memory-level parallelism at
+// batch 32, where every MobileNet layer is one or two workgroup rounds and a workgroup's life is a
+// chain of memory round trips:
+//   * wave (wm, wn) owns 16 output channels x (16*TM) pixels and PRELOADS its whole weight panel
+//     (16 x K, up to WPF k-steps of 32) into registers before anything else — no weight load sits
+//     on the dependent path; deeper K re-fills the ring right after each use;
+//   * the depthwise tile (BM x Cin) is produced by all 768 threads with one or two pixels per thread
+//     and all 9/18 tap loads in flight at once; depthwise weights are read from LDS (broadcast-free,
+//     consecutive lanes -> consecutive 16-byte slots) instead of living in 36 VGPRs;
+//   * phase B touches only LDS + MFMA.
+// Requires 768 % (Cin_pitch/8) == 0.
+// -------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int WPF>
+__global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
+    constexpr int NT = 768;
+    constexpr int BM = WM * 16 * TM, BN = WN * 16;
+    constexpr int CS_LD = BN + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
+    yk_half *Ws = As + (size_t)BM * LDA;             // depthwise weights [9][Cp]
+    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int nk = Kp >> 5;
+#define YK_STAMP(k)                                                                                  \
+    if (a.dbg && tid == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)wall_clock64();
+    YK_STAMP(0)
+
+    // (1) this wave's pointwise weight panel -> registers
+    const int nrow = n0 + wn * 16 + fr;
+    const yk_half *wrow = a.w + (size_t)nrow * a.K + fk;
+    half8 wq[WPF];
+#pragma unroll
+    for (int s = 0; s < WPF; ++s) {
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s < nk && nrow < a.N && s * 32 + fk < a.K) v = *reinterpret_cast<const half8 *>(wrow + s * 32);
+        wq[s] = v;
+    }
+    // (2) depthwise weights -> LDS
+    for (int v = tid; v < 9 * (Cp >> 3); v += NT)
+        *reinterpret_cast<half8 *>(Ws + v * 8) = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)v * 8);
+
+    // (3) depthwise tap loads: item j of this thread is pixel pl + j*PP, channel group g
+    const int G = Cp >> 3;
+    const int pl = (int)yk_div(tid, a.fd_g), g = tid - pl * G;
+    const int PP = NT / G;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
+    const float4 sc0 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8);
+    const float4 sc1 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8 + 4);
+    const float4 bs0 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8);
+    const float4 bs1 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8 + 4);
+    const bool dcap = a.dw_cap < 3.0e38f;
+    // zero the K padding (Cp..Kp)
+    {
+        const int padv = (Kp - Cp) >> 3;
+        for (int v = tid; v < BM * padv; v += NT) {
+            const int p = v / padv, c = v - p * padv;
+            *reinterpret_cast<half8 *>(As + p * LDA + Cp + c * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __syncthreads();                                 // Ws visible
+    YK_STAMP(1)
+    for (int p = pl; p < BM; p += 2 * PP) {
+        u32x4 x0[9], x1[9];
+        const bool two = (p + PP) < BM;
+        dw_issue(a, rs, (uint32_t)min(m0 + p, a.M - 1), (uint32_t)g * 16u, x0);
+        if (two) dw_issue(a, rs, (uint32_t)min(m0 + p + PP, a.M - 1), (uint32_t)g * 16u, x1);
+        const yk_half *wl = Ws + g * 8;
+        *reinterpret_cast<half8 *>(As + p * LDA + g * 8) =
+            dcap ? dw_finish<true>(x0, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap)
+                 : dw_finish<false>(x0, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap);
+        if (two)
+            *reinterpret_cast<half8 *>(As + (p + PP) * LDA + g * 8) =
+                dcap ? dw_finish<true>(x1, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap)
+                     : dw_finish<false>(x1, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap);
+    }
+    YK_STAMP(2)
+    __syncthreads();
+    YK_STAMP(3)
+
+    // (4) GEMM from LDS + registers
+    floatx4 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; kt += WPF) {
+#pragma unroll
+        for (int s = 0; s < WPF; ++s) {
+            if (kt + s < nk) {
+                half8 xf[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LDA + (kt + s) * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[s], xf[i], acc[i], 0, 0, 0);
+                if (kt + s + WPF < nk) {
+                    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (nrow < a.N && (kt + s + WPF) * 32 + fk < a.K)
+                        v = *reinterpret_cast<const half8 *>(wrow + (kt + s + WPF) * 32);
+                    wq[s] = v;
+                }
+            }
+        }
+    }
+    YK_STAMP(4)
+    __syncthreads();
+    YK_STAMP(5)
+
+    // (5) epilogue through LDS
+    yk_half *Cs = reinterpret_cast<yk_half *>(yk_smem);
+    const int nl = wn * 16 + (lane >> 4) * 4, n = n0 + nl;
+    const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n);
+    const float4 bs = *reinterpret_cast<const float4 *>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
+        half4 h = {(yk_half)yk_actf(acc[i][0] * sc.x + bs.x, a.slope, a.cap), (yk_half)yk_actf(acc[i][1] * sc.y + bs.y, a.slope, a.cap),
+                   (yk_half)yk_actf(acc[i][2] * sc.z + bs.z, a.slope, a.cap), (yk_half)yk_actf(acc[i][3] * sc.w + bs.w, a.slope, a.cap)};
+        if (a.res && m < a.M && n < a.resp) {
+            const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
+            h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
+                      (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
+        }
+        *reinterpret_cast<half4 *>(Cs + ml * CS_LD + nl) = h;
+    }
+    __syncthreads();
+    constexpr int VPR = BN / 8;
+    yk_half *o = reinterpret_cast<yk_half *>(a.out);
+    for (int v = tid; v < BM * VPR; v += NT) {
+        const int row = v / VPR, cv = v - row * VPR, m = m0 + row, col = n0 + cv * 8;
+        if (m < a.M && col < a.outp)
+            *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) = *reinterpret_cast<const half8 *>(Cs + row * CS_LD + cv * 8);
+    }
+    YK_STAMP(6)
+    if (a.dbg && tid == 0)
+        a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] =
+            ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#undef YK_STAMP
+}
+
+// -------------------------------------------------------------------------------------
+// "lr" (low-register, high-residency) variant for the large-spatial / few-channel blocks (Cin <= 128):
+// these layers stream tens of MB with almost no reuse, so what matters is how many independent
+// loads the CU keeps in flight.  256-thread workgroups, <= 64..80 VGPRs -> 6-8 workgroups per CU
+// running out of phase; the pointwise GEMM walks N in passes of 48 columns so the accumulator stays
+// 12*TM registers; depthwise weights come from LDS.
+// -------------------------------------------------------------------------------------
+template <int TM>
+__global__ void __launch_bounds__(256) fused_lr_kernel(const igemm_args a) {
+    constexpr int NT = 256, BM = 64 * TM, TN = 3;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    const int npass = (a.N + 47) / 48, CS_LD = npass * 48 + 8;
+    yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
+    yk_half *Ws = As + (size_t)BM * LDA;
+    yk_half *Cs = Ws + (size_t)9 * Cp;
+    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int nk = Kp >> 5;
+
+    for (int v = tid; v < 9 * (Cp >> 3); v += NT)
+        *reinterpret_cast<half8 *>(Ws + v * 8) = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)v * 8);
+    {
+        const int padv = (Kp - Cp) >> 3;
+        for (int v = tid; v < BM * padv; v += NT) {
+            const int p = v / padv, c = v - p * padv;
+            *reinterpret_cast<half8 *>(As + p * LDA + Cp + c * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: depthwise, one pixel-octet per iteration (rows past M reuse the last pixel; never stored)
+    {
+        const int G = Cp >> 3;
+        const int pl = (int)yk_div(tid, a.fd_g), g = tid - pl * G;
+        const int PP = NT / G;
+        if (pl < PP) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
+            const float4 sc0 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8);
+            const float4 sc1 = *reinterpret_cast<const float4 *>(a.dw_scale + g * 8 + 4);
+            const float4 bs0 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8);
+            const float4 bs1 = *reinterpret_cast<const float4 *>(a.dw_bias + g * 8 + 4);
+            const yk_half *wl = Ws + g * 8;
+            const bool capped = a.dw_cap < 3.0e38f;
+            for (int p = pl; p < BM; p += PP) {
+                u32x4 x[9];
+                dw_issue(a, rs, (uint32_t)min(m0 + p, a.M - 1), (uint32_t)g * 16u, x);
+                const half8 h = capped ? dw_finish<true>(x, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap)
+                                       : dw_finish<false>(x, wl, Cp, sc0, sc1, bs0, bs1, a.dw_slope, a.dw_cap);
+                *reinterpret_cast<half8 *>(As + p * LDA + g * 8) = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: N in passes of 48 columns; wave w owns rows [w*16*TM, (w+1)*16*TM)
+    const int nl4 = (lane >> 4) * 4;
+    const bool capped_o = a.cap < 3.0e38f;
+    for (int ps = 0; ps < npass; ++ps) {
+        floatx4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            half8 wf[TN], xf[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ps * 48 + j * 16 + fr, k = kt * 32 + fk;
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (n < a.N && k < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + k);
+                wf[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                xf[i] = *reinterpret_cast<const half8 *>(As + ((wid * TM + i) * 16 + fr) * LDA + kt * 32 + fk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = ps * 48 + j * 16 + nl4;
+            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + nl);
+            const float4 bs = *reinterpret_cast<const float4 *>(a.bias + nl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = (wid * TM + i) * 16 + fr, m = m0 + ml;
+                half4 h = capped_o ? epi4<true>(acc[i][j], sc, bs, a.slope, a.cap) : epi4<false>(acc[i][j], sc, bs, a.slope, a.cap);
+                if (a.res && m < a.M && nl < a.resp) {
+                    const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + nl);
+                    h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
+                              (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
+                }
+                *reinterpret_cast<half4 *>(Cs + ml * CS_LD + nl) = h;
+            }
+        }
+    }
+    __syncthreads();
+    const int VPR = a.outp >> 3;
+    yk_half *o = reinterpret_cast<yk_half *>(a.out);
+    for (int v = tid; v < BM * VPR; v += NT) {
+        const int row = (int)yk_div(v, a.fd_vpr), cv = v - row * VPR, m = m0 + row;
+        if (m < a.M)
+            *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + cv * 8) = *reinterpret_cast<const half8 *>(Cs + row * CS_LD + cv * 8);
+    }
+}
+
+template <int TM>
+static int launch_lr(const igemm_args &a, hipStream_t st) {
+    constexpr int BM = 64 * TM;
+    const int Kp = (a.c0p + 31) & ~31, npass = (a.N + 47) / 48;
+    const size_t lds = ((size_t)BM * (Kp + 8) + (size_t)9 * a.c0p + (size_t)BM * (npass * 48 + 8)) * 2;
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_lr_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((fused_lr_kernel<TM>), dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
+    return YK_OK;
+}
+
+// -------------------------------------------------------------------------------------
+// "wave" variant: barrier-free, every wavefront is autonomous.  The MFMA pixel-operand layout of
+// v_mfma_f32_16x16x32_f16 is  lane -> (pixel = lane&15, channel octet = lane>>4): exactly one
+// depthwise work item (pixel, 8 channels).  So each lane computes the depthwise result of ITS
+// fragment in registers and feeds it straight to the MFMA — the depthwise tile never exists in LDS
+// or HBM, there is no __syncthreads() after the prologue, and waves drift freely so one wave's
+// loads overlap another's math.  Pointwise weights (N x K fp16, <= 72 KB) are re-read per wave from L1/L2.
+// One wave = 16*TM consecutive output pixels x all N = 16*TN channels.
+// -------------------------------------------------------------------------------------
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) fused_wave_kernel(const igemm_args a) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Cp = a.c0p, nk = (Cp + 31) >> 5;
+    yk_half *Ws = reinterpret_cast<yk_half *>(yk_smem);          // depthwise weights [9][Cp]
+    float *Sb = reinterpret_cast<float *>(Ws + (size_t)9 * Cp);  // depthwise scale[Cp], bias[Cp]
+    for (int v = tid; v < 9 * (Cp >> 3); v += 256)
+        *reinterpret_cast<half8 *>(Ws + v * 8) = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)v * 8);
+    for (int v = tid; v < Cp; v += 256) {
+        Sb[v] = a.dw_scale[v];
+        Sb[Cp + v] = a.dw_bias[v];
+    }
+    __syncthreads();                                              // the only block-level barrier
+
+    const int fr = lane & 15, kg = lane >> 4;
+    const int wave = yk_xcd_tile(blockIdx.x, gridDim.x) * 4 + wid;
+    const int mb = wave * 16 * TM;
+    if (mb >= a.M) return;
+    const int hw = a.Ho * a.Wo;
+    const yk_half *base[TM];
+    int iy0[TM], ix0[TM];
+    bool valid[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mb + i * 16 + fr;
+        valid[i] = m < a.M;
+        const uint32_t mm = valid[i] ? m : 0;
+        const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * hw;
+        const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+        iy0[i] = (int)oy * a.dw_stride - a.dw_pad_t;
+        ix0[i] = (int)ox * a.dw_stride - a.dw_pad_l;
+        base[i] = a.in0 + (size_t)b * a.dw_Hi * a.dw_Wi * Cp;
+    }
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int c0 = (kt * 4 + kg) * 8;                         // this lane's channel octet
+        const bool cv = c0 < Cp;
+        // pointwise weight fragments of this k-step (independent of the depthwise result)
+        half8 wf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 16 + fr;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < a.N && c0 < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + c0);
+            wf[j] = v;
+        }
+        // depthwise taps of all TM pixels of this lane: 9*TM loads in flight
+        u32x4 x[TM][9];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                    u32x4 v = {0, 0, 0, 0};
+                    if (cv && valid[i] && (unsigned)iy < (unsigned)a.dw_Hi && (unsigned)ix < (unsigned)a.dw_Wi)
+                        v = *reinterpret_cast<const u32x4 *>(base[i] + (size_t)(iy * a.dw_Wi + ix) * Cp + c0);
+                    x[i][ky * 3 + kx] = v;
+                }
+        half8 xf[TM];
+        const int cc = cv ? c0 : 0;
+        const float4 sc0 = *reinterpret_cast<const float4 *>(Sb + cc), sc1 = *reinterpret_cast<const float4 *>(Sb + cc + 4);
+        const float4 bs0 = *reinterpret_cast<const float4 *>(Sb + Cp + cc), bs1 = *reinterpret_cast<const float4 *>(Sb + Cp + cc + 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(Ws + (size_t)t * Cp + cc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fma_mix_lo(d[2 * j], x[i][t][j], w[j]);
+                    fma_mix_hi(d[2 * j + 1], x[i][t][j], w[j]);
+                }
+            }
+            half8 h;
+            h[0] = (yk_half)yk_actf(d[0] * sc0.x + bs0.x, a.dw_slope, a.dw_cap);
+            h[1] = (yk_half)yk_actf(d[1] * sc0.y + bs0.y, a.dw_slope, a.dw_cap);
+            h[2] = (yk_half)yk_actf(d[2] * sc0.z + bs0.z, a.dw_slope, a.dw_cap);
+            h[3] = (yk_half)yk_actf(d[3] * sc0.w + bs0.w, a.dw_slope, a.dw_cap);
+            h[4] = (yk_half)yk_actf(d[4] * sc1.x + bs1.x, a.dw_slope, a.dw_cap);
+            h[5] = (yk_half)yk_actf(d[5] * sc1.y + bs1.y, a.dw_slope, a.dw_cap);
+            h[6] = (yk_half)yk_actf(d[6] * sc1.z + bs1.z, a.dw_slope, a.dw_cap);
+            h[7] = (yk_half)yk_actf(d[7] * sc1.w + bs1.w, a.dw_slope, a.dw_cap);
+            xf[i] = (cv && valid[i]) ? h : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+
+    // epilogue: lane holds channels n..n+3 of pixel fr -> one 8-byte store per (pixel tile, channel tile)
+    yk_half *o = reinterpret_cast<yk_half *>(a.out);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = j * 16 + kg * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n);
+        const float4 bs = *reinterpret_cast<const float4 *>(a.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mb + i * 16 + fr;
+            half4 h = {(yk_half)yk_actf(acc[i][j][0] * sc.x + bs.x, a.slope, a.cap), (yk_half)yk_actf(acc[i][j][1] * sc.y + bs.y, a.slope, a.cap),
+                       (yk_half)yk_actf(acc[i][j][2] * sc.z + bs.z, a.slope, a.cap), (yk_half)yk_actf(acc[i][j][3] * sc.w + bs.w, a.slope, a.cap)};
+            if (m < a.M && n < a.outp) {
+                if (a.res && n < a.resp) {
+                    const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
+                    h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
+                              (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
+                }
+                *reinterpret_cast<half4 *>(o + (size_t)m * a.outp + n) = h;
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+static int launch_wave(const igemm_args &a, hipStream_t st) {
+    const size_t lds = (size_t)9 * a.c0p * 2 + (size_t)2 * a.c0p * 4;
+    const int waves = (a.M + 16 * TM - 1) / (16 * TM);
+    hipLaunchKernelGGL((fused_wave_kernel<TM, TN>), dim3((waves + 3) / 4), dim3(256), lds, st, a);
+    return YK_OK;
+}
+
+template <int WM, int WN, int TM, int WPF>
+static int launch_wide(const igemm_args &a, hipStream_t st) {
+    constexpr int BM = WM * 16 * TM, BN = WN * 16;
+    const int Kp = (a.c0p + 31) & ~31;
+    size_t lds = (size_t)BM * (Kp + 8) * 2 + (size_t)9 * a.c0p * 2, cs = (size_t)BM * (BN + 8) * 2;
+    if (cs > lds) lds = cs;
+    static size_t attr_lds = 64 * 1024;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_wide_kernel<WM, WN, TM, WPF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((fused_wide_kernel<WM, WN, TM, WPF>), grid, dim3(768), lds, st, a);
+    return YK_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int IT>
 static int launch_fused(const igemm_args &a, hipStream_t st) {
     const int Kp = (a.c0p + 31) & ~31;
     size_t lds = (size_t)BM * (Kp + 8) * 2, cs = (size_t)BM * (BN + 8) * 2;
     if (cs > lds) lds = cs;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dwpw_kernel<BM, BN, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static size_t attr_lds = 64 * 1024;   // opt in to > 64 KiB dynamic LDS only when a layer needs it
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_dwpw_kernel<BM, BN, WM, WN, IT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
     }
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((fused_dwpw_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, a);
+    hipLaunchKernelGGL((fused_dwpw_kernel<BM, BN, WM, WN, IT>), grid, dim3(64 * WM * WN), lds, st, a);
     return YK_OK;
 }
 
@@ -753,6 +1249,37 @@ bool yk_igemm_fused_ok(int c0p, int cout) {
     return c0p % 8 == 0 && (size_t)32 * (Kp + 8) * 2 <= 96 * 1024 && (256 / (c0p >> 3)) >= 1 && cout >= 8;
 }
 int yk_igemm_fused_pick(const igemm_args &a) {
+    const int G = a.c0p >> 3;
+    static const bool wide = getenv("YK_WIDE") ? getenv("YK_WIDE")[0] != '0' : true;
+    static const int wavek = getenv("YK_WAVE") ? atoi(getenv("YK_WAVE")) : 0;   // 0 off, 1/2 = TM
+    if (wavek && a.c0p <= 192 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) {
+        const int tn = (a.N + 15) / 16;
+        if (tn <= 3) return wavek == 1 ? WAVE_T1_N3 : WAVE_T2_N3;
+        if (tn <= 6) return wavek == 1 ? WAVE_T1_N6 : WAVE_T2_N6;
+        return wavek == 1 ? WAVE_T1_N12 : WAVE_T2_N12;
+    }
+    static const bool lr = getenv("YK_LR") ? getenv("YK_LR")[0] != '0' : true;
+    if (lr && a.c0p <= 128 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) return (a.c0p <= 48) ? LR_T2 : LR_T1;
+    if (wide && 768 % G == 0 && a.c0p <= 768) {
+        // aim at one or two depthwise items per thread: BM * G ~ 768..1536
+        if (a.N <= 48) return WIDE_4x3_T4;                                  // BM 256
+        if (a.N <= 96) return (G <= 6) ? WIDE_2x6_T4 : WIDE_2x6_T2;         // BM 128 / 64
+        // N >= 192: waves split N (12 x 16 columns per slice).  Fit the grid to ONE round of 256 CUs:
+        // a workgroup's life here is a fixed chain of memory round trips, so 3 rounds cost 3x.
+        const int ns = (a.N + 191) / 192;
+        const int tiles_m = 256 / ns > 0 ? 256 / ns : 1;
+        const int tm = ((a.M + tiles_m - 1) / tiles_m + 15) / 16;
+        const bool deep = a.c0p > 192;
+        if (!deep) {
+            if (tm <= 2) return WIDE_1x12_T2;
+            if (tm <= 4) return WIDE_1x12_T4;
+            if (tm <= 5) return WIDE_1x12_T5;
+            return WIDE_1x12_T9;
+        }
+        if (tm <= 2) return WIDE_1x12_T2_D12;
+        if (tm <= 3) return WIDE_1x12_T3_D12;
+        return WIDE_1x12_T5_D12;
+    }
     if (a.N <= 48) return FUSED_128x48;
     if (a.N <= 96) return FUSED_128x96;
     const long m64 = (a.M + 63) / 64;
@@ -760,15 +1287,34 @@ int yk_igemm_fused_pick(const igemm_args &a) {
     return FUSED_32x192;
 }
 const char *yk_igemm_fused_name(int cfg) {
-    static const char *n[] = {"fused_128x48", "fused_128x96", "fused_64x192", "fused_32x192"};
+    static const char *n[] = {"fused_128x48", "fused_128x96", "fused_64x192", "fused_32x192", "wide_256x48", "wide_128x96",
+                              "wide_64x96", "wide_64x192", "wide_32x192", "wide_32x192d12", "lr_64", "lr_128", "wave16_n48", "wave32_n48", "wave16_n96", "wave32_n96", "wave16_n192", "wave32_n192", "wide_48x192d12", "wide_80x192d12", "wide_80x192", "wide_144x192"};
     return (cfg >= 0 && cfg < FUSED_NUM) ? n[cfg] : "?";
 }
 int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
-    case FUSED_128x48: return launch_fused<128, 48, 4, 1>(a, st);
-    case FUSED_128x96: return launch_fused<128, 96, 4, 1>(a, st);
-    case FUSED_64x192: return launch_fused<64, 192, 2, 2>(a, st);
-    case FUSED_32x192: return launch_fused<32, 192, 1, 4>(a, st);
+    case FUSED_128x48: return launch_fused<128, 48, 4, 1, 1>(a, st);
+    case FUSED_128x96: return launch_fused<128, 96, 4, 1, 1>(a, st);
+    case FUSED_64x192: return launch_fused<64, 192, 2, 2, 2>(a, st);
+    case FUSED_32x192: return launch_fused<32, 192, 1, 4, 2>(a, st);
+    case WIDE_4x3_T4: return launch_wide<4, 3, 4, 6>(a, st);
+    case WIDE_2x6_T4: return launch_wide<2, 6, 4, 6>(a, st);
+    case WIDE_2x6_T2: return launch_wide<2, 6, 2, 6>(a, st);
+    case WIDE_1x12_T4: return launch_wide<1, 12, 4, 6>(a, st);
+    case WIDE_1x12_T2: return launch_wide<1, 12, 2, 6>(a, st);
+    case WIDE_1x12_T2_D12: return launch_wide<1, 12, 2, 12>(a, st);
+    case WIDE_1x12_T3_D12: return launch_wide<1, 12, 3, 12>(a, st);
+    case WIDE_1x12_T5_D12: return launch_wide<1, 12, 5, 12>(a, st);
+    case WIDE_1x12_T5: return launch_wide<1, 12, 5, 6>(a, st);
+    case WIDE_1x12_T9: return launch_wide<1, 12, 9, 6>(a, st);
+    case LR_T1: return launch_lr<1>(a, st);
+    case LR_T2: return launch_lr<2>(a, st);
+    case WAVE_T1_N3: return launch_wave<1, 3>(a, st);
+    case WAVE_T2_N3: return launch_wave<2, 3>(a, st);
+    case WAVE_T1_N6: return launch_wave<1, 6>(a, st);
+    case WAVE_T2_N6: return launch_wave<2, 6>(a, st);
+    case WAVE_T1_N12: return launch_wave<1, 12>(a, st);
+    case WAVE_T2_N12: return launch_wave<2, 12>(a, st);
     }
     yk_set_error("yk_launch_igemm_fused: bad config %d", cfg);
     return YK_ERR_ARG;

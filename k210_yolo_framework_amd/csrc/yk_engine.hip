@@ -96,6 +96,8 @@ struct yk_plan {
     std::vector<int> outputs;
     unsigned *d_imgmax = nullptr;
     float *d_slab = nullptr;
+    long long *d_dbg = nullptr;
+    int dbg_launch = -1;
     size_t slab_bytes = 0;
     int in_h = 0, in_w = 0;
     int last_batch = 0;
@@ -367,6 +369,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             g.fd_hw = yk_make_fastdiv((uint32_t)(Y.h * Y.w));
             g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
             g.split_k = 1;
+            g.in0_bytes = (uint32_t)std::min<size_t>((size_t)max_batch * s0->h * s0->w * s0->cp * 2, 0xffffffffu);
             tinfo *dst = &Y;
             if (add_of[i] >= 0) {
                 const int32_t *q = ops + (size_t)add_of[i] * YK_OP_FIELDS;
@@ -378,6 +381,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             const bool f32 = dst->net_out;
             g.out = f32 ? (void *)dst->d32 : (void *)dst->d;
             g.outp = f32 ? dst->c : dst->cp;
+            g.fd_vpr = yk_make_fastdiv((uint32_t)std::max(1, g.outp >> 3));
             if (!g.out) {
                 yk_set_error("op %d: output tensor not allocated", i);
                 return fail(YK_ERR_UNSUPPORTED);
@@ -399,6 +403,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
                 g.dw_pad_t = dwo[YK_F_PAD_T]; g.dw_pad_l = dwo[YK_F_PAD_L];
                 g.dw_Hi = dwX->h; g.dw_Wi = dwX->w;
                 yk_act_params(g.dw_act, 0.f, &g.dw_slope, &g.dw_cap);
+                g.fd_g = yk_make_fastdiv((uint32_t)(c0p >> 3));
                 dw_flops = 2.0 * X.h * X.w * 9 * c0;
                 dw_bytes = ((double)dwX->h * dwX->w * c0 + (double)X.h * X.w * c0) * 2;
             }
@@ -510,6 +515,7 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
             igemm_args g = l.g;
             g.M = batch * l.Ho * l.Wo;
             g.slab = p->d_slab;
+            g.dbg = (li == p->dbg_launch) ? p->d_dbg : nullptr;
             rc = g.dw_w ? yk_launch_igemm_fused(l.cfg, g, st) : yk_launch_igemm(l.cfg, g, st);
             if (!rc && g.split_k > 1) rc = yk_launch_splitk_reduce(g, l.out_f32, st);
         } break;
@@ -608,6 +614,26 @@ extern "C" int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_d
     const size_t pix = (size_t)batch * t.h * t.w;
     for (size_t q = 0; q < pix; ++q)
         for (int c = 0; c < t.c; ++c) h_dst[q * t.c + c] = h2f_bits(h[q * t.cp + c]);
+    return YK_OK;
+}
+
+// dev instrumentation: arm phase timestamps for launch `li`, run once (u8 path), copy out [n_wg][8] ticks (100 MHz)
+extern "C" int yk_debug_phase_stamps(yk_plan_t *p, int li, const uint8_t *d_frames, int batch, void *stream,
+                                     long long *h_out, int max_wg) {
+    if (!p || li < 0 || li >= (int)p->L.size()) return YK_ERR_ARG;
+    YK_HIP(hipSetDevice(p->device));
+    if (!p->d_dbg) {
+        int rc = dev_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 8 * 65536, true);
+        if (rc) return rc;
+    }
+    YK_HIP(hipMemset(p->d_dbg, 0, sizeof(long long) * 8 * 65536));
+    p->dbg_launch = li;
+    int rc = run_plan(p, d_frames, 0, batch, stream);
+    p->dbg_launch = -1;
+    if (rc) return rc;
+    YK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (max_wg > 65536) max_wg = 65536;
+    YK_HIP(hipMemcpy(h_out, p->d_dbg, sizeof(long long) * 8 * max_wg, hipMemcpyDeviceToHost));
     return YK_OK;
 }
 
