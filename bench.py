@@ -103,10 +103,9 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
+        from k210_yolo_framework_amd import shard
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, dist, device='cuda')
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 

@@ -109,7 +109,37 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     }
     __syncthreads();
     int kept = 0;
-    if (n <= YK_NMS_MAXC) {
+    if (n <= 512 && max_out <= 64) {
+        // Fast path (the usual case: a few dozen candidates per class).  TF's own formulation: visit the
+        // candidates in descending score order and test each against the boxes selected so far.  The selected
+        // boxes live one per lane in registers, so a candidate costs one IoU + one ballot: no LDS writes, no barriers.
+        int *ord = reinterpret_cast<int *>(L.box + YK_NMS_MAXC) - 512;   // tail of the box array is free (n <= 512)
+        for (int c = lane; c < n; c += 64) {                              // rank sort: (score desc, box index asc)
+            const float sc_c = L.s[c];
+            const int ic = L.idx[c];
+            int r = 0;
+            for (int j = 0; j < n; ++j) {
+                const float sj = L.s[j];
+                r += (sj > sc_c || (sj == sc_c && L.idx[j] < ic)) ? 1 : 0;
+            }
+            ord[r] = c;
+        }
+        __syncthreads();
+        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n && kept < max_out; ++i) {
+            const int pos = ord[i];
+            const float4 cb = L.box[pos];
+            const bool hit = (lane < kept) && (tf_iou(cb, mine) > iou_thresh);
+            if (__ballot(hit) == 0ull) {
+                if (lane == kept) mine = cb;
+                if (lane == 0) {
+                    og[kept] = L.idx[pos];
+                    os[kept] = L.s[pos];
+                }
+                ++kept;
+            }
+        }
+    } else if (n <= YK_NMS_MAXC) {
         kept = yk_wave_greedy_nms(
             n, L.s, L.idx, L.box, iou_thresh, max_out, [](const float4 &a, const float4 &d) { return tf_iou(d, a); },
             [&](int rank, int pos) {

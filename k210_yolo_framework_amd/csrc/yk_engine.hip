@@ -59,7 +59,7 @@ float h2f_bits(uint16_t h) {
     return f;
 }
 
-enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD, K_U8MAX };
+enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD, K_U8MAX, K_REDUCE };
 enum { T_REAL = 0, T_UP = 1, T_CAT = 2 };
 
 struct tinfo {
@@ -475,6 +475,14 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
         }
         l.name = nm;
         p->L.push_back(l);
+        if (l.kind == K_IGEMM && l.g.split_k > 1) {   // deterministic finishing pass of split-K, its own launch
+            launch r = l;
+            r.kind = K_REDUCE;
+            r.name = std::string("splitk_reduce") + std::to_string(l.g.split_k) + "_" + std::to_string(l.g.N);
+            r.flops = 0;
+            r.bytes = ((double)l.g.split_k * 4 + 2) * l.Ho * l.Wo * l.g.ldn;   // slabs read (fp32) + tile written (fp16)
+            p->L.push_back(r);
+        }
     }
     if (p->slab_bytes) {
         if ((rc = dev_alloc(p, (void **)&p->d_slab, p->slab_bytes, true))) return fail(rc);
@@ -517,7 +525,12 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
             g.slab = p->d_slab;
             g.dbg = (li == p->dbg_launch) ? p->d_dbg : nullptr;
             rc = g.dw_w ? yk_launch_igemm_fused(l.cfg, g, st) : yk_launch_igemm(l.cfg, g, st);
-            if (!rc && g.split_k > 1) rc = yk_launch_splitk_reduce(g, l.out_f32, st);
+        } break;
+        case K_REDUCE: {
+            igemm_args g = l.g;
+            g.M = batch * l.Ho * l.Wo;
+            g.slab = p->d_slab;
+            rc = yk_launch_splitk_reduce(g, l.out_f32, st);
         } break;
         case K_DW: {
             dw_args d = l.d;

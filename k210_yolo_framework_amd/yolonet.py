@@ -1,0 +1,130 @@
+"""Host-side mirror of the reference's model plugin API (`models/yolonet.py`).
+
+The reference selects a network by name (`eval(model_def)`, keras_inference.py:77-78, keras_train.py:49-50)
+and calls it as  net([H,W,3], anchor_num, class_num, alpha=...) -> (yolo_model, yolo_model_warpper)  where
+`yolo_model` emits [N,h,w,A*(5+C)] per scale and `yolo_model_warpper` the same data reshaped to
+[N,h,w,A,5+C] (yolonet.py:40-44).  The same four names are registered here; the objects returned expose
+the methods the reference scripts use — `load_weights`, `predict`, `save_weights` — with numpy in / list of
+numpy out and the reference's shapes and (h, w, anchor, entry) order.
+
+All arithmetic happens in libyolo_hip.so (engine.Plan); without a GPU `predict` raises.
+
+Weights: a flat `.npz` with Keras-layout arrays (`<layer>/kernel` HWIO, `<layer>/bias`, `<bn>/gamma|beta|
+moving_mean|moving_variance`).  A Keras-HDF5 reader is row N1 of SURVEY.md 8(f) (h5py is not in this image).
+Unlike the reference (yolonet.py:16-21,146,182) building a model does NOT require pre-train files: it
+starts from seeded random weights until `load_weights` is called.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import netspec as ns
+
+
+class YoloModel:
+    """`wrapped=False` -> yolo_model ([N,h,w,A*(5+C)]), `wrapped=True` -> yolo_model_warpper ([N,h,w,A,5+C])."""
+
+    def __init__(self, spec: ns.NetSpec, shared: dict, wrapped: bool):
+        self.spec = spec
+        self._s = shared          # weights + lazily built engine plan, shared by both views of one network
+        self.wrapped = wrapped
+
+    # -- Keras-like surface -------------------------------------------------------------------------
+    @property
+    def input_shape(self):
+        return (None, *self.spec.in_hw, 3)
+
+    @property
+    def output_shape(self):
+        e = 5 + self.spec.class_num
+        a = self.spec.anchor_num
+        return [(None, h, w, a, e) if self.wrapped else (None, h, w, a * e) for (h, w) in self.spec.out_hw()]
+
+    def get_weights(self) -> Dict[str, np.ndarray]:
+        return self._s['weights']
+
+    def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        want = self.spec.init_weights(seed=0)
+        for k, v in want.items():
+            if k not in weights:
+                raise KeyError(f'missing weight {k}')
+            if tuple(weights[k].shape) != tuple(v.shape):
+                raise ValueError(f'{k}: shape {weights[k].shape} != {v.shape}')
+        self._s['weights'] = {k: np.asarray(weights[k], np.float32) for k in want}
+        self._drop_plan()
+
+    def load_weights(self, path: str) -> None:
+        """keras_inference.py:80 / keras_train.py:52-57."""
+        with np.load(path) as z:
+            self.set_weights({k: z[k] for k in z.files})
+
+    def save_weights(self, path: str) -> None:
+        """keras_train.py:105-109 (`keras.models.save_model(yolo_model, ...)`)."""
+        np.savez(path, **self._s['weights'])
+
+    def _drop_plan(self):
+        p = self._s.pop('plan', None)
+        if p is not None:
+            p.close()
+
+    def _plan(self, batch: int):
+        from . import engine
+        p = self._s.get('plan')
+        if p is None or p.max_batch < batch:
+            self._drop_plan()
+            p = engine.Plan(self.spec, self._s['weights'], max_batch=max(batch, 1))
+            self._s['plan'] = p
+        return p
+
+    def predict(self, x: np.ndarray) -> List[np.ndarray]:
+        """keras_inference.py:88.  x: [N,H,W,3] float (already `img / np.max(img)`) or uint8 frames
+        (then the normalisation of tools/utils.py:405 is done on the GPU)."""
+        import torch
+        x = np.asarray(x)
+        if x.ndim == 3:
+            x = x[None]
+        n = x.shape[0]
+        plan = self._plan(n)
+        if x.dtype == np.uint8:
+            plan.run_u8(torch.from_numpy(np.ascontiguousarray(x)).cuda())
+        else:
+            plan.run_f32(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        torch.cuda.synchronize()
+        outs = [o[:n].cpu().numpy() for o in plan.outputs()]
+        if self.wrapped:
+            e = 5 + self.spec.class_num
+            outs = [o.reshape(n, o.shape[1], o.shape[2], self.spec.anchor_num, e) for o in outs]
+        return outs
+
+
+def _build(name: str, input_shape, anchor_num: int, class_num: int, **kwargs) -> Tuple[YoloModel, YoloModel]:
+    alpha = kwargs.get('alpha', 1.0)
+    spec = ns.NETWORKS[name](list(input_shape), anchor_num, class_num, alpha=alpha)
+    shared = {'weights': spec.init_weights(seed=1)}
+    return YoloModel(spec, shared, False), YoloModel(spec, shared, True)
+
+
+def yolo_mobilev1(input_shape, anchor_num, class_num, **kwargs):
+    """models/yolonet.py:12-46."""
+    return _build('yolo_mobilev1', input_shape, anchor_num, class_num, **kwargs)
+
+
+def yolo_mobilev2(input_shape, anchor_num, class_num, **kwargs):
+    """models/yolonet.py:49-104."""
+    return _build('yolo_mobilev2', input_shape, anchor_num, class_num, **kwargs)
+
+
+def tiny_yolo(input_shape, anchor_num, class_num, **kwargs):
+    """models/yolonet.py:107-158."""
+    return _build('tiny_yolo', input_shape, anchor_num, class_num, **kwargs)
+
+
+def yolo(input_shape, anchor_num, class_num, **kwargs):
+    """models/yolonet.py:161-191."""
+    return _build('yolo', input_shape, anchor_num, class_num, **kwargs)
+
+
+# the reference uses eval(model_def); a dict keeps the same names without eval
+MODEL_DEFS = {'yolo_mobilev1': yolo_mobilev1, 'yolo_mobilev2': yolo_mobilev2, 'tiny_yolo': tiny_yolo, 'yolo': yolo}
