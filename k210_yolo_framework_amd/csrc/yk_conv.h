@@ -50,7 +50,9 @@ struct igemm_args {
     yk_fastdiv fd_hw, fd_wo;    // division by Ho*Wo and Wo
     yk_fastdiv fd_g;            // division by c0p/8 (fused depthwise producer)
     yk_fastdiv fd_vpr;          // division by outp/8 (flat tile store)
+    yk_fastdiv fd_ctp;          // division by c0p+c1p (k -> tap)
     uint32_t in0_bytes;         // byte size of in0 (buffer-load bounds)
+    uint32_t in1_bytes, w_bytes;
     int split_k;                // >1: partial sums go to `slab` [split][M][ldn] fp32, finished by yk_launch_splitk_reduce
     float *slab;
     int ldn;

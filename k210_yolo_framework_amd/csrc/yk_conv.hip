@@ -38,6 +38,7 @@ __device__ __forceinline__ int yk_xcd_tile(int bid, int nt) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+#define YK_MAXP 8   /* partial maxima per image (u8_max_kernel -> first_conv_kernel) */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- depthwise 3x3 work item = (output pixel, 8 channels) --------------------------------------
@@ -420,7 +421,12 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const first_args a) {
         sc[tid] = a.scale[tid];
         bs[tid] = a.bias[tid];
     }
-    if (!a.in_f32) lut[tid] = (float)tid / (float)a.img_max[b];     // img / np.max(img), tools/utils.py:405
+    if (!a.in_f32) {                                                 // img / np.max(img), tools/utils.py:405
+        unsigned mx = 0;
+#pragma unroll
+        for (int j = 0; j < YK_MAXP; ++j) mx = max(mx, a.img_max[b * YK_MAXP + j]);
+        lut[tid] = (float)tid / (float)mx;
+    }
     __syncthreads();
     const int pix = blockIdx.x * 256 + tid;
     if (pix >= a.Ho * a.Wo) return;
@@ -479,42 +485,50 @@ int yk_launch_first(const first_args &a, hipStream_t st) {
     return YK_OK;
 }
 
-// per-image max of u8 frames -> img_max[b]; one 1024-thread workgroup per image, plain store
-__global__ void __launch_bounds__(1024) u8_max_kernel(const uint8_t *__restrict__ f, size_t per_image, int vec_ok,
-                                                      unsigned *__restrict__ img_max) {
-    __shared__ unsigned part[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// per-image max of u8 frames: YK_MAXP workgroups per image write partial maxima img_max[b*YK_MAXP + j]
+// (plain stores, no atomics, no memset); the stem conv folds the partials when it builds its LUT.
+__global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__ f, size_t per_image, int vec_ok,
+                                                     unsigned *__restrict__ img_max) {
+    __shared__ unsigned part[4];
+    const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
     const uint8_t *p = f + (size_t)b * per_image;
     unsigned m = 0;
+    const size_t t = (size_t)j * 256 + tid, nth = (size_t)YK_MAXP * 256;
     if (vec_ok) {
         const uint4 *q = reinterpret_cast<const uint4 *>(p);
         const size_t n16 = per_image / 16;
-        for (size_t i = tid; i < n16; i += 1024) {
+        size_t i = t;
+        for (; i + 3 * nth < n16; i += 4 * nth) {          // 4 independent 16-byte loads in flight
+            const uint4 v[4] = {q[i], q[i + nth], q[i + 2 * nth], q[i + 3 * nth]};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    m = max(m, max(max(w[k] & 0xffu, (w[k] >> 8) & 0xffu), max((w[k] >> 16) & 0xffu, w[k] >> 24)));
+            }
+        }
+        for (; i < n16; i += nth) {
             const uint4 v = q[i];
             const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                m = max(m, max(max(w[j] & 0xffu, (w[j] >> 8) & 0xffu), max((w[j] >> 16) & 0xffu, w[j] >> 24)));
+            for (int k = 0; k < 4; ++k)
+                m = max(m, max(max(w[k] & 0xffu, (w[k] >> 8) & 0xffu), max((w[k] >> 16) & 0xffu, w[k] >> 24)));
         }
-        for (size_t i = n16 * 16 + tid; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
+        for (size_t r = n16 * 16 + t; r < per_image; r += nth) m = max(m, (unsigned)p[r]);
     } else {
-        for (size_t i = tid; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
+        for (size_t i = t; i < per_image; i += nth) m = max(m, (unsigned)p[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((tid & 63) == 0) part[tid >> 6] = m;
     __syncthreads();
-    if (tid < 16) {
-        m = part[tid];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-        if (tid == 0) img_max[b] = m;
-    }
+    if (tid == 0) img_max[b * YK_MAXP + j] = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
 int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st) {
     const int vec_ok = (per_image % 16 == 0) && ((uintptr_t)frames % 16 == 0);
-    hipLaunchKernelGGL(u8_max_kernel, dim3(batch), dim3(1024), 0, st, frames, per_image, vec_ok, img_max);
+    hipLaunchKernelGGL(u8_max_kernel, dim3(YK_MAXP, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
     return YK_OK;
 }
 

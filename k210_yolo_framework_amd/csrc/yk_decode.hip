@@ -185,19 +185,29 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     if (lane == 0) cnt[b * C + c] = kept;
 }
 
-// grid (batch), 64 threads: class-major concatenation (keras_inference.py:133-135)
-__global__ void __launch_bounds__(64) compact_py_kernel(int ntot, int C, int max_out, const float4 *__restrict__ boxes,
-                                                        const int *__restrict__ sel_g, const float *__restrict__ sel_s,
-                                                        const int *__restrict__ cnt, float *__restrict__ dets,
-                                                        int *__restrict__ counts) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    int base = 0;
-    for (int c = 0; c < C; ++c) {
-        const int k = cnt[b * C + c];
-        for (int j = lane; j < k; j += 64) {
+// grid (batch), 256 threads: class-major concatenation (keras_inference.py:133-135); one thread per (class, rank) slot
+__global__ void __launch_bounds__(256) compact_py_kernel(int ntot, int C, int max_out, const float4 *__restrict__ boxes,
+                                                         const int *__restrict__ sel_g, const float *__restrict__ sel_s,
+                                                         const int *__restrict__ cnt, float *__restrict__ dets,
+                                                         int *__restrict__ counts) {
+    extern __shared__ int base[];                   // [C + 1] exclusive prefix of the per-class counts
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) {
+            base[c] = acc;
+            acc += cnt[b * C + c];
+        }
+        base[C] = acc;
+        counts[b] = acc;
+    }
+    __syncthreads();
+    for (int slot = tid; slot < C * max_out; slot += 256) {
+        const int c = slot / max_out, j = slot - c * max_out;
+        if (j < base[c + 1] - base[c]) {
             const int g = sel_g[((size_t)b * C + c) * max_out + j];
             const float4 bb = boxes[(size_t)b * ntot + g];
-            float *d = dets + ((size_t)b * C * max_out + base + j) * 6;
+            float *d = dets + ((size_t)b * C * max_out + base[c] + j) * 6;
             d[0] = bb.x;
             d[1] = bb.y;
             d[2] = bb.z;
@@ -205,9 +215,7 @@ __global__ void __launch_bounds__(64) compact_py_kernel(int ntot, int C, int max
             d[4] = sel_s[((size_t)b * C + c) * max_out + j];
             d[5] = (float)c;
         }
-        base += k;
     }
-    if (lane == 0) counts[b] = base;
 }
 
 extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
@@ -268,7 +276,7 @@ extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pr
                        scores_t);
     hipLaunchKernelGGL(nms_py_kernel, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out,
                        boxes, scores_t, sel_g, sel_s, cnt);
-    hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(64), 0, st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
+    hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(256), (a.C + 1) * sizeof(int), st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
                        d_dets, d_counts);
     YK_HIP(hipGetLastError());
     return YK_OK;

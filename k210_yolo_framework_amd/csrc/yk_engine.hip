@@ -262,7 +262,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
         }
         if (rc) return fail(rc);
     }
-    rc = dev_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch, true);
+    rc = dev_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 8, true);   // YK_MAXP partials per image
     if (rc) return fail(rc);
 
     // pass 2: launches
@@ -362,14 +362,21 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             void *dwt;
             if ((rc = upload(p, &dwt, w.data(), w.size() * 2))) return fail(rc);
             g.w = (const yk_half *)dwt;
+            g.w_bytes = (uint32_t)(w.size() * 2);
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &g.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &g.bias))) return fail(rc);
             g.act = o[YK_F_ACT]; g.alpha = alpha;
             yk_act_params(g.act, g.alpha, &g.slope, &g.cap);
             g.fd_hw = yk_make_fastdiv((uint32_t)(Y.h * Y.w));
             g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
+            g.fd_ctp = yk_make_fastdiv((uint32_t)(c0p + c1p));
             g.split_k = 1;
             g.in0_bytes = (uint32_t)std::min<size_t>((size_t)max_batch * s0->h * s0->w * s0->cp * 2, 0xffffffffu);
+            g.in1_bytes = s1 ? (uint32_t)std::min<size_t>((size_t)max_batch * s1->h * s1->w * s1->cp * 2, 0xffffffffu) : 0u;
+            if (g.in0_bytes >= 0x40000000u || g.in1_bytes >= 0x40000000u) {
+                yk_set_error("op %d: activation tensor >= 1 GiB; lower max_batch", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
             tinfo *dst = &Y;
             if (add_of[i] >= 0) {
                 const int32_t *q = ops + (size_t)add_of[i] * YK_OP_FIELDS;
