@@ -57,6 +57,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay a captured HIP graph instead of launching eagerly '
+                    '(measured: no gain, the step is GPU-bound; kept as an option)')
     args = ap.parse_args()
 
     import torch
@@ -93,12 +95,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):
         step()
+    sync_all()
+    # The step is ~27 back-to-back launches on one stream with no host decision in between; it can be captured
+    # once as a HIP graph and replayed (same kernels, same work).
+    graph = None
+    if args.graph:
+        try:
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap_stream):
+                step()
+                cap_stream.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap_stream):
+                    g_dets, g_counts = step()
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:   # capture is an optimisation of the launch path only
+            print(f'[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
+            graph = None
+    run = graph.replay if graph is not None else step
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dets, counts = step()
+        run()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -140,6 +164,7 @@ def main():
             'config': {'workload': 'configs[1]: yolo_mobilev1 alpha=0.75, network tensor 224x320x3 (320x240 frame, SURVEY F1), '
                                    '20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
+                       'launch_mode': 'hip-graph replay' if graph is not None else 'eager',
                        'algorithmic_GB_per_step': round(tot_bytes / 1e9, 4), 'algorithmic_GFLOP_per_step': round(tot_flops / 1e9, 2),
                        'parallelism': f'image-sharded x{world}, no collective'},
             'roofline': roof,
