@@ -194,6 +194,22 @@ typedef struct {
 int yk_region_batched(const yk_region_cfg_t *cfg, const float *d_input, int batch, float *d_output /* may be NULL */,
                       float *d_boxes, float *d_probs, void *stream);
 
+/* ---- training step, loss level (tools/utils.py:708-793 create_loss_fn, :662-705 calc_ignore_mask,
+ *      tools/custom.py:13-75 Yolo_Precision/Yolo_Recall) for ONE output layer.
+ * d_y_true / d_y_pred: device fp32 [batch][out_h][out_w][A][5+C] (labels from Helper.box_to_label / raw outputs).
+ * d_loss[6]   = {total, xy, wh, obj, noobj, cls}, each already divided by cfg->batch_size like the reference.
+ * d_grad      = dL/dy_pred, same shape as d_y_pred (NULL to skip) — what TF autodiff yields for this graph.
+ * d_ignore    = ignore mask [batch][out_h][out_w][A] (NULL to skip).
+ * d_counts[3] = running {tp, fp, fn}; this batch's counts are ADDED (Keras metric assign_add); NULL to skip. */
+typedef struct {
+    int32_t out_h, out_w, anchor_num, class_num;
+    float anchors[YK_MAX_ANCHORS][2];       /* Helper.anchors[layer] */
+    float obj_thresh, iou_thresh, obj_weight, noobj_weight, wh_weight;
+    int32_t batch_size;                     /* Helper.batch_size (the divisor in utils.py:771-787) */
+} yk_loss_cfg_t;
+int yk_yolo_loss(const yk_loss_cfg_t *cfg, const float *d_y_true, const float *d_y_pred, int batch, float *d_loss,
+                 float *d_grad, float *d_ignore, float *d_counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

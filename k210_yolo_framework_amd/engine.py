@@ -44,6 +44,13 @@ class RegionCfg(C.Structure):
                 ('stride_y', C.c_int64), ('stride_x', C.c_int64)]
 
 
+class LossCfg(C.Structure):
+    """yk_loss_cfg_t"""
+    _fields_ = [('out_h', C.c_int32), ('out_w', C.c_int32), ('anchor_num', C.c_int32), ('class_num', C.c_int32),
+                ('anchors', (C.c_float * 2) * YK_MAX_ANCHORS), ('obj_thresh', C.c_float), ('iou_thresh', C.c_float),
+                ('obj_weight', C.c_float), ('noobj_weight', C.c_float), ('wh_weight', C.c_float), ('batch_size', C.c_int32)]
+
+
 def library_path() -> Path:
     return LIB_PATH
 
@@ -60,7 +67,7 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched', 'yk_yolo_loss',
                    'region_layer_init'):
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
@@ -247,3 +254,29 @@ def region_batched(inp, W: int, H: int, A: int, Cn: int, anchor, threshold: floa
     _check(lib().yk_region_batched(C.byref(cfg), _ptr(inp), C.c_int(B), _ptr(out) if out is not None else None,
                                    _ptr(boxes), _ptr(probs), _stream(stream)), 'yk_region_batched')
     return out, boxes, probs
+
+
+def yolo_loss(y_true, y_pred, anchors_l, obj_thresh, iou_thresh, obj_weight, noobj_weight, wh_weight, batch_size=None,
+              counts=None, want_grad=True, want_ignore=False, stream=None):
+    """tools/utils.py:741-791 loss_fn + custom.py metrics for one layer on the GPU.
+    y_true / y_pred: cuda fp32 [B,h,w,A,5+C].  -> (loss[6] = total,xy,wh,obj,noobj,cls ; grad | None ; ignore | None).
+    `counts` (cuda fp32 [3], running tp/fp/fn) is updated in place when given."""
+    import torch
+    require_gpu()
+    assert y_true.is_cuda and y_pred.is_cuda and y_true.shape == y_pred.shape and y_pred.dtype == torch.float32
+    y_true, y_pred = y_true.contiguous(), y_pred.contiguous()
+    B, h, w, A, E = y_pred.shape
+    cfg = LossCfg()
+    cfg.out_h, cfg.out_w, cfg.anchor_num, cfg.class_num = h, w, A, E - 5
+    for n, (aw, ah) in enumerate(np.asarray(anchors_l, np.float32)):
+        cfg.anchors[n][0], cfg.anchors[n][1] = float(aw), float(ah)
+    cfg.obj_thresh, cfg.iou_thresh = obj_thresh, iou_thresh
+    cfg.obj_weight, cfg.noobj_weight, cfg.wh_weight = obj_weight, noobj_weight, wh_weight
+    cfg.batch_size = int(batch_size if batch_size else B)
+    loss = torch.empty(6, dtype=torch.float32, device=y_pred.device)
+    grad = torch.empty_like(y_pred) if want_grad else None
+    ign = torch.empty((B, h, w, A), dtype=torch.float32, device=y_pred.device) if want_ignore else None
+    _check(lib().yk_yolo_loss(C.byref(cfg), _ptr(y_true), _ptr(y_pred), C.c_int(B), _ptr(loss),
+                              _ptr(grad) if grad is not None else None, _ptr(ign) if ign is not None else None,
+                              _ptr(counts) if counts is not None else None, _stream(stream)), 'yk_yolo_loss')
+    return loss, grad, ign

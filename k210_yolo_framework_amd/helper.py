@@ -236,3 +236,61 @@ def tf_iou(pred_xy, pred_wh, vaild_xy, vaild_wh):
     iw = np.maximum(np.minimum(b1_maxes, b2_maxes) - np.maximum(b1_mins, b2_mins), 0.)
     inter = iw[..., 0] * iw[..., 1]
     return inter / (b1_wh[..., 0] * b1_wh[..., 1] + b2_wh[..., 0] * b2_wh[..., 1] - inter)
+
+
+# ---- loss / metrics (tools/utils.py:708-793, tools/custom.py:13-75): same names, GPU arithmetic ---------------
+def create_loss_fn(h: Helper, obj_thresh: float, iou_thresh: float, obj_weight: float, noobj_weight: float,
+                   wh_weight: float, layer: int):
+    """tools/utils.py:708-793.  Returns loss_fn(y_true, y_pred) -> scalar loss (cuda tensor); the five terms, the
+    gradient dL/dy_pred and the ignore mask of the last call are kept on the function object
+    (`loss_fn.terms`, `loss_fn.grad`).  y_* are cuda fp32 tensors [B,h,w,A,5+C]; all arithmetic is in
+    libyolo_hip.so (yk_yolo_loss)."""
+    from . import engine
+
+    def loss_fn(y_true, y_pred):
+        loss, grad, _ = engine.yolo_loss(y_true, y_pred, h.anchors[layer], obj_thresh, iou_thresh, obj_weight,
+                                         noobj_weight, wh_weight, batch_size=h.batch_size)
+        loss_fn.terms, loss_fn.grad = loss, grad
+        return loss[0]
+    loss_fn.terms = loss_fn.grad = None
+    return loss_fn
+
+
+class _YoloMetric:
+    """Running tp/fp/fn over batches, thresholding the RAW confidence logit exactly like custom.py:33."""
+
+    def __init__(self, thresholds=None, name=None):
+        self.thresholds = 0.5 if thresholds is None else thresholds
+        self.name = name
+        self._counts = None
+
+    def reset_states(self):
+        self._counts = None
+
+    def update_state(self, y_true, y_pred, sample_weight=None, *, anchors_l=None):
+        import torch
+        from . import engine
+        if self._counts is None:
+            self._counts = torch.zeros(3, dtype=torch.float32, device=y_pred.device)
+        A = y_pred.shape[3]
+        anc = anchors_l if anchors_l is not None else np.ones((A, 2), np.float32)
+        engine.yolo_loss(y_true, y_pred, anc, self.thresholds, 0.5, 1.0, 1.0, 1.0, counts=self._counts, want_grad=False)
+
+    def _c(self):
+        return [0.0, 0.0, 0.0] if self._counts is None else [float(v) for v in self._counts.cpu()]
+
+
+class Yolo_Precision(_YoloMetric):
+    """tools/custom.py:13-43: tp / (tp + fp), div_no_nan."""
+
+    def result(self):
+        tp, fp, _ = self._c()
+        return tp / (tp + fp) if tp + fp > 0 else 0.0
+
+
+class Yolo_Recall(_YoloMetric):
+    """tools/custom.py:46-75: tp / (tp + fn), div_no_nan."""
+
+    def result(self):
+        tp, _, fn = self._c()
+        return tp / (tp + fn) if tp + fn > 0 else 0.0
