@@ -194,6 +194,13 @@ typedef struct {
 int yk_region_batched(const yk_region_cfg_t *cfg, const float *d_input, int batch, float *d_output /* may be NULL */,
                       float *d_boxes, float *d_probs, void *stream);
 
+/* ---- pre-processing (the step immediately before the path) ------------------------------
+ * Helper._process_img letterbox (tools/utils.py:378-399) for a batch of equally sized u8 frames:
+ * d_src [batch][src_h][src_w][3] -> d_dst [batch][dst_h][dst_w][3], bilinear, zero fill, truncating cast.
+ * (The `img / np.max(img)` that follows, utils.py:405, is fused into yk_run_u8.) */
+int yk_letterbox_u8(const uint8_t *d_src, int batch, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
+                    void *stream);
+
 /* ---- training step, loss level (tools/utils.py:708-793 create_loss_fn, :662-705 calc_ignore_mask,
  *      tools/custom.py:13-75 Yolo_Precision/Yolo_Recall) for ONE output layer.
  * d_y_true / d_y_pred: device fp32 [batch][out_h][out_w][A][5+C] (labels from Helper.box_to_label / raw outputs).

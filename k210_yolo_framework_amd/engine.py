@@ -67,7 +67,7 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched', 'yk_yolo_loss',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init'):
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
@@ -280,3 +280,15 @@ def yolo_loss(y_true, y_pred, anchors_l, obj_thresh, iou_thresh, obj_weight, noo
                               _ptr(grad) if grad is not None else None, _ptr(ign) if ign is not None else None,
                               _ptr(counts) if counts is not None else None, _stream(stream)), 'yk_yolo_loss')
     return loss, grad, ign
+
+
+def letterbox_u8(frames, dst_hw, stream=None):
+    """GPU Helper._process_img letterbox (tools/utils.py:378-399): cuda uint8 [B,h,w,3] -> cuda uint8 [B,H,W,3]."""
+    import torch
+    require_gpu()
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[-1] == 3
+    B, sh, sw, _ = frames.shape
+    out = torch.empty((B, int(dst_hw[0]), int(dst_hw[1]), 3), dtype=torch.uint8, device=frames.device)
+    _check(lib().yk_letterbox_u8(_ptr(frames), C.c_int(B), C.c_int(sh), C.c_int(sw), _ptr(out), C.c_int(out.shape[1]),
+                                 C.c_int(out.shape[2]), _stream(stream)), 'yk_letterbox_u8')
+    return out

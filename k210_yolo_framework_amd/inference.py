@@ -14,7 +14,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .helper import INFO, NOTE, Helper, VOC_ANCHORS, letterbox_bilinear
+from .helper import INFO, NOTE, Helper, VOC_ANCHORS
 from .yolonet import MODEL_DEFS
 
 
@@ -22,15 +22,17 @@ def detect(h: Helper, model, orig_imgs, obj_thresh: float, iou_thresh: float):
     """orig_imgs: list of HxWx3 uint8 arrays -> list of [K,6] (top,left,bottom,right,score,class) numpy."""
     import torch
     from . import engine
-    frames, shapes = [], []
-    for img in orig_imgs:
-        scale, translation = h.letterbox_params(img.shape[:2])
-        frames.append(letterbox_bilinear(img, tuple(h.in_hw[0]), float(scale[0]), translation))
-        shapes.append(img.shape[:2])
-    frames = np.ascontiguousarray(np.stack(frames), np.uint8)
-    n = len(frames)
+    shapes = [img.shape[:2] for img in orig_imgs]
+    n = len(orig_imgs)
+    in_hw = tuple(int(v) for v in h.in_hw[0])
+    if len(set(shapes)) == 1:
+        src = torch.from_numpy(np.ascontiguousarray(np.stack(orig_imgs), np.uint8)).cuda()
+        frames = engine.letterbox_u8(src, in_hw)                       # yk_letterbox_u8 (tools/utils.py:378-399)
+    else:
+        frames = torch.cat([engine.letterbox_u8(torch.from_numpy(np.ascontiguousarray(im[None], np.uint8)).cuda(), in_hw)
+                            for im in orig_imgs])
     plan = model._plan(n)
-    plan.run_u8(torch.from_numpy(frames).cuda())
+    plan.run_u8(frames.contiguous())
     cfg = engine.make_decode_cfg(h.anchors, h.class_num, h.in_hw[0], h.out_hw)
     dets, counts = engine.decode_py(cfg, plan.outputs(), n, np.asarray(shapes, np.float32), obj_thresh, iou_thresh)
     torch.cuda.synchronize()
