@@ -40,6 +40,7 @@ __device__ __forceinline__ int yk_xcd_tile(int bid, int nt) {
 
 #define YK_MAXP 8   /* partial maxima per image (u8_max_kernel -> first_conv_kernel) */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+extern __shared__ __attribute__((aligned(16))) unsigned char yk_smem[];
 
 // ---- depthwise 3x3 work item = (output pixel, 8 channels) --------------------------------------
 // Taps are fetched with raw buffer loads: out-of-image taps get an offset >= the buffer size and the
@@ -100,10 +101,84 @@ __device__ __forceinline__ half4 epi4(const floatx4 c, const float4 sc, const fl
                  (yk_half)yk_act2<CAPPED>(c[2] * sc.z + bs.z, slope, cap), (yk_half)yk_act2<CAPPED>(c[3] * sc.w + bs.w, slope, cap)};
 }
 
+template <int BM, int BN, int WM, int WN, int OUT, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const igemm_args &a, floatx4 (&acc)[TM][TN], yk_half *lds, int m0, int n0, int tid,
+                                               int lane, int wm, int wn) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int CS_LD = BN + 8;
+    const int fr = lane & 15;
+    // ---- epilogue: lane holds channels n..n+3 (acc regs) of pixel m = lane&15
+    const int nl4 = (lane >> 4) * 4;
+    if constexpr (OUT == 2) {
+        float *slab = a.slab + (size_t)blockIdx.z * a.M * a.ldn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 16 + nl4;
+                if (m < a.M && n < a.ldn)
+                    *reinterpret_cast<float4 *>(slab + (size_t)m * a.ldn + n) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    } else {
+        float4 sc[TN], bs[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + nl4;
+            sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);   // arrays padded past N with zeros
+            bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 16 + nl4, n = n0 + nl;
+                const float v0 = yk_actf(acc[i][j][0] * sc[j].x + bs[j].x, a.slope, a.cap);
+                const float v1 = yk_actf(acc[i][j][1] * sc[j].y + bs[j].y, a.slope, a.cap);
+                const float v2 = yk_actf(acc[i][j][2] * sc[j].z + bs[j].z, a.slope, a.cap);
+                const float v3 = yk_actf(acc[i][j][3] * sc[j].w + bs[j].w, a.slope, a.cap);
+                if constexpr (OUT == 1) {
+                    if (m < a.M) {
+                        float *o = reinterpret_cast<float *>(a.out) + (size_t)m * a.outp + n;
+                        if (n + 0 < a.N) o[0] = v0;
+                        if (n + 1 < a.N) o[1] = v1;
+                        if (n + 2 < a.N) o[2] = v2;
+                        if (n + 3 < a.N) o[3] = v3;
+                    }
+                } else {
+                    half4 h = {(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
+                    if (a.res && m < a.M && n < a.resp) {
+                        // Add(inputs, x): the conv result is first rounded to its fp16 storage value
+                        const half4 r = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
+                        h = half4{(yk_half)((float)h[0] + (float)r[0]), (yk_half)((float)h[1] + (float)r[1]),
+                                  (yk_half)((float)h[2] + (float)r[2]), (yk_half)((float)h[3] + (float)r[3])};
+                    }
+                    *reinterpret_cast<half4 *>(lds + ml * CS_LD + nl) = h;
+                }
+            }
+        }
+        if constexpr (OUT == 0) {
+            __syncthreads();
+            constexpr int VPR = BN / 8;
+            yk_half *o = reinterpret_cast<yk_half *>(a.out);
+            for (int v = tid; v < BM * VPR; v += NT) {
+                const int row = v / VPR, cv = v - row * VPR, m = m0 + row, col = n0 + cv * 8;
+                if (m < a.M && col < a.outp)
+                    *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) =
+                        *reinterpret_cast<const half8 *>(lds + row * CS_LD + cv * 8);
+            }
+        }
+    }
+}
+
 // =====================================================================================
 // implicit GEMM.  OUT: 0 = fp16 through LDS, 1 = fp32 direct (network outputs), 2 = split-K slab
 // =====================================================================================
-template <int BM, int BN, int WM, int WN, int BK, int OUT>
+template <int BM, int BN, int WM, int WN, int BK, int OUT, bool UNI>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int LD = BK + 8;                      // LDS row pitch (halfs): 16 B aligned, spreads banks
@@ -112,10 +187,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
     constexpr int A_VEC = BM * CPR, B_VEC = BN * CPR;
     constexpr int A_IT = (A_VEC + NT - 1) / NT, B_IT = (B_VEC + NT - 1) / NT;
     constexpr int STAGE = (BM + BN) * LD;
-    constexpr int CS_LD = BN + 8;
-    constexpr int CS_HALFS = (OUT == 0) ? BM * CS_LD : 0;
-    constexpr int LDS_HALFS = (2 * STAGE > CS_HALFS) ? 2 * STAGE : CS_HALFS;
-    __shared__ __attribute__((aligned(16))) yk_half lds[LDS_HALFS];
+    yk_half *lds = reinterpret_cast<yk_half *>(yk_smem);   // dynamic: max(2 stages, output tile), see launch_cfg
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -130,6 +202,151 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
     const int per = (nk_all + a.split_k - 1) / a.split_k;
     const int kt0 = blockIdx.z * per;
     const int nk = min(per, nk_all - kt0);
+
+    if constexpr (UNI) {
+        // ------------------------------------------------------------------------------------------------
+        // Uniform-tap fast path: (c0p+c1p) % BK == 0 and c0p % BK == 0, so within one k-step every thread is in the
+        // SAME filter tap and the SAME concat source.  Tap / source / channel offset become scalars, the per-row work
+        // per k-step shrinks to ~10 VALU, and every load is an unconditional raw buffer load (out-of-image taps,
+        // rows >= M, columns >= N get an offset past num_records and return zeros): a branch-free loop body in which
+        // hipcc can keep TWO k-steps of loads in flight behind counted s_waitcnt vmcnt(N).
+        // ------------------------------------------------------------------------------------------------
+        int ry0[A_IT], rx0[A_IT];
+        uint32_t rbo0[A_IT], rbo1[A_IT], rmask[A_IT], wro[B_IT];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int v = tid + it * NT, row = v / CPR, m = m0 + row;
+            const bool ok = v < A_VEC && m < a.M;
+            const uint32_t mm = ok ? m : 0;
+            const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * (a.Ho * a.Wo);
+            const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+            ry0[it] = (int)oy * a.stride - a.pad_t;
+            rx0[it] = (int)ox * a.stride - a.pad_l;
+            rbo0[it] = b * (uint32_t)(H0 * W0 * a.c0p * 2) + kc * 16u;
+            rbo1[it] = b * (uint32_t)(a.Hi * a.Wi * a.c1p * 2) + kc * 16u;
+            uint32_t msk = 0;
+            for (int t = 0; t < taps; ++t) {
+                const int ky = (a.ks == 3) ? t / 3 : 0, kx = t - ky * a.ks;
+                if (ok && (unsigned)(ry0[it] + ky) < (unsigned)a.Hi && (unsigned)(rx0[it] + kx) < (unsigned)a.Wi) msk |= 1u << t;
+            }
+            rmask[it] = msk;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int vv = tid + it * NT, row = vv / CPR, n = n0 + row;
+            wro[it] = (vv < B_VEC && n < a.N) ? (uint32_t)(n * a.K) * 2u + kc * 16u : YK_OOB;
+        }
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in1 ? a.in1 : a.in0), 0, a.in1_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+        u32x4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
+        // Incremental addressing: (tap, cin) are loop-carried SCALARS; the per-row tap offsets `aoff` are recomputed
+        // only when the segment (tap, concat source) changes, i.e. every Ctp/BK (8-12) k-steps; a k-step then costs
+        // one vector add per load.  `lim` = first k-step that belongs to the next split (loads past it return zeros).
+        const int lim = kt0 + nk;
+        int step = kt0;
+        uint32_t tap = yk_div((uint32_t)kt0 * BK, a.fd_ctp);
+        int cin = kt0 * BK - (int)tap * Ctp;
+        uint32_t aoff[A_IT];
+        bool src1 = false;
+        auto retap = [&]() {
+            src1 = cin >= a.c0p;
+            const int ky = (a.ks == 3) ? (int)tap / 3 : 0, kx = (int)tap - ky * a.ks;
+            const bool tlive = (int)tap < taps;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int iy = ry0[it] + ky, ix = rx0[it] + kx;
+                const bool inb = tlive && ((rmask[it] >> tap) & 1u);
+                uint32_t o;
+                if (src1) {
+                    o = rbo1[it] + (uint32_t)((iy * a.Wi + ix) * a.c1p - a.c0p) * 2u;     // + cin*2 added per step
+                } else {
+                    const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
+                    o = rbo0[it] + (uint32_t)((sy * W0 + sx) * a.c0p) * 2u;
+                }
+                aoff[it] = inb ? o : YK_OOB;
+            }
+        };
+        retap();
+        auto gload = [&](u32x4 (&ra)[A_IT], u32x4 (&rbv)[B_IT]) {
+            const bool live = step < lim;
+            const uint32_t cs = (uint32_t)cin * 2u, ws = (uint32_t)step * (BK * 2u);
+            if (src1) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it)
+                    ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rs1, live ? aoff[it] + cs : YK_OOB, 0, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it)
+                    ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rs0, live ? aoff[it] + cs : YK_OOB, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) rbv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw, live ? wro[it] + ws : YK_OOB, 0, 0);
+            ++step;
+            cin += BK;
+            if (cin == Ctp) {
+                cin = 0;
+                ++tap;
+            }
+            if (cin == 0 || cin == a.c0p) retap();       // segment change (uniform, rare)
+        };
+        auto sstore = [&](const u32x4 (&ra)[A_IT], const u32x4 (&rbv)[B_IT], int stage) {
+            yk_half *As = lds + stage * STAGE, *Bs = As + BM * LD;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int v = tid + it * NT;
+                if (v < A_VEC) *reinterpret_cast<u32x4 *>(As + (v / CPR) * LD + kc * 8) = ra[it];
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                const int v = tid + it * NT;
+                if (v < B_VEC) *reinterpret_cast<u32x4 *>(Bs + (v / CPR) * LD + kc * 8) = rbv[it];
+            }
+        };
+        floatx4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int fr = lane & 15, fk = (lane >> 4) * 8;
+        auto compute = [&](int stage) {
+            const yk_half *As = lds + stage * STAGE, *Bs = As + BM * LD;
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                half8 wf[TN], xf[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * LD + ks * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * LD + ks * 32 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+        };
+        if (nk > 0) {
+            gload(ra0, rb0);                           // step kt0
+            sstore(ra0, rb0, 0);
+            __syncthreads();
+            gload(ra0, rb0);                           // S0 <- step kt0+1
+            gload(ra1, rb1);                           // S1 <- step kt0+2
+            for (int kt = 0; kt < nk; kt += 2) {      // steps past the end of this split load zeros
+                compute(0);
+                sstore(ra0, rb0, 1);
+                gload(ra0, rb0);                       // kt+3
+                __syncthreads();
+                compute(1);
+                sstore(ra1, rb1, 0);
+                gload(ra1, rb1);                       // kt+4
+                __syncthreads();
+            }
+        }
+        igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
+        return;
+    }
 
     // ---- per-thread A rows (fixed over the K loop)
     int rb[A_IT], riy[A_IT], rix[A_IT];
@@ -236,72 +453,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const igemm_args a)
         }
     }
 
-    // ---- epilogue: lane holds channels n..n+3 (acc regs) of pixel m = lane&15
-    const int nl4 = (lane >> 4) * 4;
-    if constexpr (OUT == 2) {
-        float *slab = a.slab + (size_t)blockIdx.z * a.M * a.ldn;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 16 + nl4;
-                if (m < a.M && n < a.ldn)
-                    *reinterpret_cast<float4 *>(slab + (size_t)m * a.ldn + n) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            }
-        }
-        return;
-    } else {
-        float4 sc[TN], bs[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 16 + nl4;
-            sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);   // arrays padded past N with zeros
-            bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ml = (wm * TM + i) * 16 + fr, m = m0 + ml;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wn * TN + j) * 16 + nl4, n = n0 + nl;
-                const float v0 = yk_actf(acc[i][j][0] * sc[j].x + bs[j].x, a.slope, a.cap);
-                const float v1 = yk_actf(acc[i][j][1] * sc[j].y + bs[j].y, a.slope, a.cap);
-                const float v2 = yk_actf(acc[i][j][2] * sc[j].z + bs[j].z, a.slope, a.cap);
-                const float v3 = yk_actf(acc[i][j][3] * sc[j].w + bs[j].w, a.slope, a.cap);
-                if constexpr (OUT == 1) {
-                    if (m < a.M) {
-                        float *o = reinterpret_cast<float *>(a.out) + (size_t)m * a.outp + n;
-                        if (n + 0 < a.N) o[0] = v0;
-                        if (n + 1 < a.N) o[1] = v1;
-                        if (n + 2 < a.N) o[2] = v2;
-                        if (n + 3 < a.N) o[3] = v3;
-                    }
-                } else {
-                    half4 h = {(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
-                    if (a.res && m < a.M && n < a.resp) {
-                        // Add(inputs, x): the conv result is first rounded to its fp16 storage value
-                        const half4 r = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
-                        h = half4{(yk_half)((float)h[0] + (float)r[0]), (yk_half)((float)h[1] + (float)r[1]),
-                                  (yk_half)((float)h[2] + (float)r[2]), (yk_half)((float)h[3] + (float)r[3])};
-                    }
-                    *reinterpret_cast<half4 *>(lds + ml * CS_LD + nl) = h;
-                }
-            }
-        }
-        if constexpr (OUT == 0) {
-            __syncthreads();
-            constexpr int VPR = BN / 8;
-            yk_half *o = reinterpret_cast<yk_half *>(a.out);
-            for (int v = tid; v < BM * VPR; v += NT) {
-                const int row = v / VPR, cv = v - row * VPR, m = m0 + row, col = n0 + cv * 8;
-                if (m < a.M && col < a.outp)
-                    *reinterpret_cast<half8 *>(o + (size_t)m * a.outp + col) =
-                        *reinterpret_cast<const half8 *>(lds + row * CS_LD + cv * 8);
-            }
-        }
-    }
+    igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
 }
 
 // finishing pass of split-K: sum the slabs in a fixed order (deterministic), then the conv epilogue
@@ -350,11 +502,30 @@ int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
     return YK_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool F32>
+template <int BM, int BN, int WM, int WN, int BK, bool F32, bool UNI_OK = false>
 static int launch_cfg(const igemm_args &a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
-    if (a.split_k > 1) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, 2>), grid, dim3(64 * WM * WN), 0, st, a);
-    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, F32 ? 1 : 0>), grid, dim3(64 * WM * WN), 0, st, a);
+    static const bool uni_on = getenv("YK_UNI") ? getenv("YK_UNI")[0] != '0' : true;
+    const bool uni = uni_on && UNI_OK && ((a.c0p + a.c1p) % BK == 0) && (a.c0p % BK == 0) && a.in0_bytes < YK_OOB && a.in1_bytes < YK_OOB;
+    constexpr size_t stages = (size_t)2 * (BM + BN) * (BK + 8) * 2, ctile = F32 ? 0 : (size_t)BM * (BN + 8) * 2;
+    constexpr size_t lds = stages > ctile ? stages : ctile;
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                done = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, a);
+    };
+    if (uni) {
+        if (a.split_k > 1) go(igemm_kernel<BM, BN, WM, WN, BK, 2, UNI_OK>);
+        else go(igemm_kernel<BM, BN, WM, WN, BK, F32 ? 1 : 0, UNI_OK>);
+    } else {
+        if (a.split_k > 1) go(igemm_kernel<BM, BN, WM, WN, BK, 2, false>);
+        else go(igemm_kernel<BM, BN, WM, WN, BK, F32 ? 1 : 0, false>);
+    }
     return YK_OK;
 }
 
@@ -364,7 +535,7 @@ struct igemm_cfg_info {
 };
 static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
     {128, 64, 32, "igemm_128x64"}, {128, 48, 32, "igemm_128x48"}, {128, 96, 32, "igemm_128x96"},
-    {128, 192, 32, "igemm_128x192"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 32, "igemm_128x128"},
+    {128, 192, 64, "igemm_128x192k64"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 64, "igemm_128x128k64"},
     {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}};
 
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
@@ -372,9 +543,9 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     case IGEMM_128x64: return launch_cfg<128, 64, 2, 2, 32, false>(a, st);
     case IGEMM_128x48: return launch_cfg<128, 48, 4, 1, 32, false>(a, st);
     case IGEMM_128x96: return launch_cfg<128, 96, 4, 1, 32, false>(a, st);
-    case IGEMM_128x192: return launch_cfg<128, 192, 4, 1, 32, false>(a, st);
-    case IGEMM_64x64: return launch_cfg<64, 64, 2, 2, 64, false>(a, st);
-    case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, 32, false>(a, st);
+    case IGEMM_128x192: return launch_cfg<128, 192, 2, 2, 64, false, true>(a, st);
+    case IGEMM_64x64: return launch_cfg<64, 64, 2, 2, 64, false, true>(a, st);
+    case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, 64, false, true>(a, st);
     case IGEMM_F32_64x80: return launch_cfg<64, 80, 4, 1, 64, true>(a, st);
     case IGEMM_F32_128x64: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
     }
@@ -390,6 +561,11 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     if (a.N == 48) return IGEMM_128x48;
     if (a.N == 96) return IGEMM_128x96;
     if (a.N == 192 && mt128 >= 512) return IGEMM_128x192;
+    // long-K convs are LDS-bandwidth-bound at 2x2 wave tiles (1 KB of LDS operand reads per MFMA, measured:
+    // SQ_WAIT_INST_LDS 23 %); 4x4 / 4x6 wave tiles halve that.  Parallelism comes back through split-K.
+    static const bool big = getenv("YK_BIGTILE") ? getenv("YK_BIGTILE")[0] != '0' : false;   // measured slower: 268 regs -> 1 wave/SIMD
+    if (big && a.K >= 1024 && a.N % 192 == 0 && mt128 >= 8) return IGEMM_128x192;
+    if (big && a.K >= 1024 && a.N >= 128 && mt128 >= 8) return IGEMM_128x128;
     if (a.N >= 128 && mt128 * ((a.N + 127) / 128) >= 512) return IGEMM_128x128;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;
@@ -401,7 +577,8 @@ int yk_igemm_split(int cfg, const igemm_args &a) {
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const int nk = (a.K + c.bk - 1) / c.bk;
     if (tiles >= 384 || nk < 6) return 1;
-    long s = (1024 + tiles - 1) / tiles;
+    const long target = ((long)c.bm * c.bn >= 128 * 128) ? 512 : 1024;
+    long s = (target + tiles - 1) / tiles;
     if (s > nk / 3) s = nk / 3;
     if (s > 16) s = 16;
     return s < 2 ? 1 : (int)s;
@@ -642,8 +819,6 @@ int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, h
 //            BEFORE phase A so they overlap it) x [K x BM] (LDS) on v_mfma_f32_16x16x32_f16;
 //            epilogue as igemm_kernel.
 // =====================================================================================
-extern __shared__ __attribute__((aligned(16))) unsigned char yk_smem[];
-
 template <int BM, int BN, int WM, int WN, int IT>
 __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_args a) {
     constexpr int NT = 64 * WM * WN;
