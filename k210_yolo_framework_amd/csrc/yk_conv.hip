@@ -540,13 +540,13 @@ static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
 
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
-    case IGEMM_128x64: return launch_cfg<128, 64, 2, 2, 32, false>(a, st);
+    case IGEMM_128x64: return launch_cfg<128, 64, 2, 2, 32, false, true>(a, st);
     case IGEMM_128x48: return launch_cfg<128, 48, 4, 1, 32, false>(a, st);
     case IGEMM_128x96: return launch_cfg<128, 96, 4, 1, 32, false>(a, st);
     case IGEMM_128x192: return launch_cfg<128, 192, 2, 2, 64, false, true>(a, st);
     case IGEMM_64x64: return launch_cfg<64, 64, 2, 2, 64, false, true>(a, st);
     case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, 64, false, true>(a, st);
-    case IGEMM_F32_64x80: return launch_cfg<64, 80, 4, 1, 64, true>(a, st);
+    case IGEMM_F32_64x80: return launch_cfg<64, 80, 4, 1, 64, true, true>(a, st);
     case IGEMM_F32_128x64: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
     }
     yk_set_error("yk_launch_igemm: bad config %d", cfg);

@@ -111,3 +111,32 @@ def test_size_independent_properties_full_batch():
             k = d[d[:, 5] == c]
             assert dr.non_max_suppression(k[:, :4], k[:, 4], 30, 0.5) == list(range(len(k)))
             assert len(k) <= 30 and (k[:, 4] >= 0.7).all()
+
+
+def test_baseline_config3_tiny_yolo_416_end_to_end():
+    """BASELINE configs[2]: tiny_yolo 416x416, two scales (13x13, 26x26); per-GPU shard of the batch of 64 = 8 images.
+    The reference's hard-coded Reshape((7,10,..)) cannot run this shape; here out_hw is derived."""
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec = ns.tiny_yolo((416, 416, 3), 3, 20)
+    assert spec.out_hw() == [(13, 13), (26, 26)]
+    w = spec.init_weights(seed=1)
+    B = 8
+    frames = np.random.default_rng(3).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)
+    plan = engine.Plan(spec, w, max_batch=B)
+    plan.run_u8(torch.from_numpy(frames).cuda())
+    cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, (416, 416), spec.out_hw())
+    dets, counts = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)
+    torch.cuda.synchronize()
+    outs = [o[:B].cpu().numpy() for o in plan.outputs()]
+    assert [o.shape for o in outs] == [(B, 13, 13, 75), (B, 26, 26, 75)]
+    ref = oracle.net_forward(spec.compile_plan(w), oracle.normalise_u8(frames[:2]), emulate_f16=True, out_ids=spec.outputs)
+    for g, r in zip(outs, ref):
+        assert np.abs(g[:2] - r).max() <= 1.5e-2 * max(1.0, np.abs(r).max())
+    rd = dr.decode_batch([o.reshape(B, o.shape[1], o.shape[2], 3, 25) for o in outs], VOC_ANCHORS, (416, 416), (416, 416), 0.7, 0.5)
+    d, c = dets.cpu().numpy(), counts.cpu().numpy()
+    for b in range(B):
+        assert c[b] == len(rd[b][0])
+        assert np.array_equal(d[b, :c[b], 5], rd[b][0][:, 5])
+        np.testing.assert_allclose(d[b, :c[b], :5], rd[b][0][:, :5], rtol=1e-5, atol=2e-3)
+    plan.close()

@@ -117,3 +117,16 @@ def test_darknet53_layers():
     n, names = _layerwise(spec, w, 2)
     assert sum('+add' in x for x in names) == 23
     assert sum('+upcat' in x for x in names) == 2
+
+
+def test_darknet53_416_fp16_stress_config_layers():
+    """BASELINE configs[4]: full YOLO (Darknet-53) 416x416, 3 scales x 3 anchors, fp16 storage — every one of the 75 convs
+    at the real shape, one launch at a time (the oracle runs on the host cores of the GPU box)."""
+    spec = ns.yolo((416, 416, 3), 3, 20)
+    assert spec.out_hw() == [(13, 13), (26, 26), (52, 52)]
+    w = spec.init_weights(seed=1)
+    for k in w:
+        if k.endswith('/gamma'):
+            w[k] = (w[k] * 0.5).astype(np.float32)
+    n, names = _layerwise(spec, w, 1)
+    assert n >= 75
