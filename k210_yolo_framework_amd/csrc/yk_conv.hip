@@ -38,7 +38,7 @@ __device__ __forceinline__ int yk_xcd_tile(int bid, int nt) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-#define YK_MAXP 8   /* partial maxima per image (u8_max_kernel -> first_conv_kernel) */
+#define YK_MAXP 32  /* partial maxima per image (u8_max_kernel -> first_conv_kernel) */
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 extern __shared__ __attribute__((aligned(16))) unsigned char yk_smem[];
 

@@ -262,7 +262,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
         }
         if (rc) return fail(rc);
     }
-    rc = dev_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 8, true);   // YK_MAXP partials per image
+    rc = dev_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32, true);   // YK_MAXP partials per image
     if (rc) return fail(rc);
 
     // pass 2: launches
