@@ -126,17 +126,31 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
         }
         __syncthreads();
         float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < n && kept < max_out; ++i) {
-            const int pos = ord[i];
-            const float4 cb = L.box[pos];
-            const bool hit = (lane < kept) && (tf_iou(cb, mine) > iou_thresh);
-            if (__ballot(hit) == 0ull) {
-                if (lane == kept) mine = cb;
-                if (lane == 0) {
-                    og[kept] = L.idx[pos];
-                    os[kept] = L.s[pos];
+        // candidates are pulled into registers 64 at a time (lane t holds the t-th best of the block) and handed
+        // out with v_readlane: the serial loop has no dependent LDS read in it
+        for (int base = 0; base < n && kept < max_out; base += 64) {
+            const int me = base + lane;
+            const int pos = (me < n) ? ord[me] : 0;
+            const float4 bb = L.box[pos];
+            const float sv = L.s[pos];
+            const int iv = L.idx[pos];
+            const int cnt = min(64, n - base);
+            for (int t = 0; t < cnt && kept < max_out; ++t) {
+                const float4 cb = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.x), t)),
+                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.y), t)),
+                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.z), t)),
+                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.w), t)));
+                const bool hit = (lane < kept) && (tf_iou(cb, mine) > iou_thresh);
+                if (__ballot(hit) == 0ull) {
+                    if (lane == kept) mine = cb;
+                    const int gi = __builtin_amdgcn_readlane(iv, t);
+                    const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), t));
+                    if (lane == 0) {
+                        og[kept] = gi;
+                        os[kept] = gs;
+                    }
+                    ++kept;
                 }
-                ++kept;
             }
         }
     } else if (n <= YK_NMS_MAXC) {
