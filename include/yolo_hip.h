@@ -217,6 +217,53 @@ typedef struct {
 int yk_yolo_loss(const yk_loss_cfg_t *cfg, const float *d_y_true, const float *d_y_pred, int batch, float *d_loss,
                  float *d_grad, float *d_ignore, float *d_counts, void *stream);
 
+/* ---- training step, network level (keras_train.py:73-98: model.fit = forward in training mode + TF autodiff +
+ *      Adam; the reference gets every one of these ops from TensorFlow 1.14).  All tensors are device fp32, NHWC,
+ *      dense (no channel padding); "M" is batch*height*width.  k210_yolo_framework_amd/train.py strings them into
+ *      the step.
+ *
+ * yk_gemm_f32: C[M][N] = alpha * op(A) * op(B) + beta * C, row-major, op = transpose when trans* != 0
+ *   (A is [M][K] or, transposed, [K][M]; B is [K][N] or [N][K]).  Conv2D 1x1 forward  Y = X * W^T,
+ *   data gradient dX = dY * W, weight gradient dW = dY^T * X (tf Conv2DBackpropInput / ...Filter). */
+int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
+                float beta, float *C, int ldc, void *stream);
+/* 3x3 Conv2D through GEMM: col [B*Ho*Wo][9*C], k = (ky*3+kx)*C + c; col2im is the adjoint (sums overlaps). */
+int yk_im2col3x3_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                     float *col, void *stream);
+int yk_col2im3x3_f32(const float *col, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                     float *dx, void *stream);
+/* DepthwiseConv2D 3x3, weights [9][C] */
+int yk_dw3x3_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t,
+                     int pad_l, float *y, void *stream);
+int yk_dw3x3_bwd_data_f32(const float *dy, const float *w, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride,
+                          int pad_t, int pad_l, float *dx, void *stream);
+int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride,
+                            int pad_t, int pad_l, float *dw, void *stream);
+/* BatchNormalization(training=True) fused with the activation that follows it (act: YK_ACT_*).
+ * fwd: batch mean / biased variance over M, y = act(gamma*(z-mean)*invstd + beta); saves mean and invstd and,
+ *      when moving_mean/moving_var are given, updates them with `momentum` (Keras: 0.99).
+ * bwd: dy is the gradient w.r.t. y; writes dz, dgamma, dbeta. */
+int yk_bn_train_fwd_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
+                        float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
+                        float *moving_var, float momentum, void *stream);
+int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M, int C, const float *gamma, const float *beta,
+                        const float *save_mean, const float *save_invstd, int act, float alpha, float *dz, float *dgamma,
+                        float *dbeta, void *stream);
+int yk_bias_add_f32(float *y, long long M, int C, const float *bias, void *stream);       /* y[m][c] += bias[c] */
+int yk_colsum_f32(const float *x, long long M, int C, float *out, void *stream);          /* out[c] = sum_m x[m][c] */
+int yk_upsample2x_bwd_f32(const float *dy, int B, int H, int W, int C, float *dx, void *stream); /* UpSampling2D(2) adjoint */
+/* MaxPooling2D(2, stride, 'same'): argmax [B][Ho][Wo][C] u8 = winning tap (first maximum, row-major window) */
+int yk_maxpool2_fwd_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *y, uint8_t *argmax,
+                        void *stream);
+int yk_maxpool2_bwd_f32(const float *dy, const uint8_t *argmax, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *dx,
+                        void *stream);
+int yk_axpy_f32(long long n, float a, const float *x, float *y, void *stream);            /* y += a*x */
+/* keras.optimizers.Adam as keras_train.py:74-76 configures it (lr, decay; beta 0.9/0.999, eps 1e-7):
+ * lr_t = lr/(1+decay*iterations) * sqrt(1-b2^t)/(1-b1^t), t = iterations+1; p -= lr_t*m/(sqrt(v)+eps).
+ * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int yk_adam_f32(long long n, float *p, const float *g, float *m, float *v, float lr, float decay, long long iterations,
+                float beta1, float beta2, float eps, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

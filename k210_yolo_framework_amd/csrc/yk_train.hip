@@ -12,6 +12,8 @@
 //   yk_bn_train_fwd_f32 / yk_bn_train_bwd_f32   BatchNormalization in training mode fused with the activation
 //   yk_upsample2x_bwd_f32, yk_axpy_f32, yk_adam_f32 (Keras Adam incl. `decay`, keras_train.py:74-76)
 #include "yk_common.h"
+#include <algorithm>
+#include <cmath>
 
 typedef float floatx4t __attribute__((ext_vector_type(4)));
 
@@ -308,7 +310,7 @@ extern "C" int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, i
     if (dev < 0) return YK_ERR_NO_DEVICE;
     int rpc;
     const int chunks = chunking((size_t)B * Ho * Wo, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 2, sizeof(float) * (size_t)chunks * 9 * C);
+    float *partial = (float *)yk_scratch(dev, stream, 12, sizeof(float) * (size_t)chunks * 9 * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, q, x, dy, partial, rpc);
@@ -419,7 +421,7 @@ extern "C" int yk_bn_train_fwd_f32(const float *z, long long M, int C, const flo
     if (dev < 0) return YK_ERR_NO_DEVICE;
     int rpc;
     const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 3, sizeof(float) * ((size_t)chunks * 2 * C + C));
+    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
     if (!partial) return YK_ERR_NOMEM;
     float *var = partial + (size_t)chunks * 2 * C;
     hipStream_t st = (hipStream_t)stream;
@@ -449,7 +451,7 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
     if (dev < 0) return YK_ERR_NO_DEVICE;
     int rpc;
     const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 3, sizeof(float) * ((size_t)chunks * 2 * C + C));
+    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_colreduce_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, 2, z, dy, (size_t)M, C, rpc, save_mean, save_invstd,
@@ -479,7 +481,7 @@ extern "C" int yk_colsum_f32(const float *x, long long M, int C, float *out, voi
     if (dev < 0) return YK_ERR_NO_DEVICE;
     int rpc;
     const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 3, sizeof(float) * ((size_t)chunks * 2 * C + C));
+    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_colreduce_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, 0, x, (const float *)nullptr, (size_t)M, C, rpc,
@@ -537,6 +539,68 @@ extern "C" int yk_adam_f32(long long n, float *p, const float *g, float *m, floa
     const double lr_t = (double)lr / (1.0 + (double)decay * (double)iterations) * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, p, g, m, v,
                        (float)lr_t, beta1, beta2, eps, grad_scale);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// MaxPool2D 2x2, padding='same' (bottom/right padded with -inf), stride 1 or 2 (tiny_yolo, yolonet.py:112-124).
+// forward records the winning tap (first maximum in row-major window order); backward gathers.
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restrict__ x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride,
+                                                          float *__restrict__ y, uint8_t *__restrict__ arg) {
+    const size_t total = (size_t)B * Ho * Wo * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t m = i / C;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((size_t)Wo * Ho));
+    float best = -__builtin_huge_valf();
+    int bt = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int iy = oy * stride + (t >> 1), ix = ox * stride + (t & 1);
+        if (iy < Hi && ix < Wi) {
+            const float v = x[(((size_t)b * Hi + iy) * Wi + ix) * C + c];
+            if (v > best) { best = v; bt = t; }
+        }
+    }
+    y[i] = best;
+    arg[i] = (uint8_t)bt;
+}
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int B, int Hi, int Wi,
+                                                          int C, int Ho, int Wo, int stride, float *__restrict__ dx) {
+    const size_t total = (size_t)B * Hi * Wi * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const int ix = (int)(p % Wi), iy = (int)((p / Wi) % Hi), b = (int)(p / ((size_t)Wi * Hi));
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ny = iy - (t >> 1), nx = ix - (t & 1);
+        if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+        const int oy = ny / stride, ox = nx / stride;
+        if (oy >= Ho || ox >= Wo) continue;
+        const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + c;
+        if (arg[o] == t) s += dy[o];
+    }
+    dx[i] = s;
+}
+extern "C" int yk_maxpool2_fwd_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *y, uint8_t *argmax,
+                                   void *stream) {
+    const size_t total = (size_t)B * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, Hi, Wi, C, Ho, Wo,
+                       stride, y, argmax);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+extern "C" int yk_maxpool2_bwd_f32(const float *dy, const uint8_t *argmax, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *dx,
+                                   void *stream) {
+    const size_t total = (size_t)B * Hi * Wi * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, argmax, B, Hi, Wi, C,
+                       Ho, Wo, stride, dx);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

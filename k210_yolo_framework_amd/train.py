@@ -1,0 +1,364 @@
+"""Training step on MI355X (keras_train.py:73-98).
+
+The reference's `train_model.fit` runs, per step: forward in training mode (batch-statistics BatchNorm), the YOLO
+loss of every output layer (tools/utils.py:708-793) plus the l2(5e-4) kernel regulariser of every DarknetConv2D
+(models/yolonet.py:245-250), TF autodiff, and keras Adam(lr, decay) (keras_train.py:73-76).  All of that is
+TensorFlow in the reference; here each arithmetic op is a HIP kernel of libyolo_hip.so (csrc/yk_train.hip,
+csrc/yk_loss.hip) called through the C-ABI, and this module is only the tape: it walks the NetSpec forwards and
+backwards.  torch supplies device buffers, views/concat (data movement) and the gradient all-reduce (RCCL).
+
+Data-parallel: one process per GPU, each with `per_rank_batch` images.  The loss divisor is the GLOBAL batch (what
+Helper.batch_size is in the single-process reference), gradients are SUM-all-reduced in one flat bucket, BatchNorm
+statistics stay per replica.  With world_size 1 this is exactly the reference's step.
+
+fp32 storage and fp32 MFMA throughout (TF1.14's default for this model)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import engine
+from . import netspec as ns
+
+L2_WEIGHT = 5e-4                 # keras.regularizers.l2(5e-4), yolonet.py:247
+BN_MOMENTUM = 0.99               # keras BatchNormalization default
+
+
+def _is_darknet_conv(name: str) -> bool:
+    """Layers built by DarknetConv2D (yolonet.py:245) carry the l2 regulariser; the MobileNet backbones do not."""
+    return name.startswith('head_conv') or name.startswith('conv2d_')
+
+
+class Trainer:
+    def __init__(self, spec: ns.NetSpec, weights: Dict[str, np.ndarray], anchors: np.ndarray, per_rank_batch: int,
+                 obj_thresh: float = 0.7, iou_thresh: float = 0.5, obj_weight: float = 1.0, noobj_weight: float = 1.0,
+                 wh_weight: float = 1.0, lr: float = 5e-4, decay: float = 0.0, device: int = 0, process_group=None,
+                 world_size: int = 1):
+        import torch
+        engine.require_gpu()
+        self.torch = torch
+        self.spec, self.B = spec, int(per_rank_batch)
+        self.dev = torch.device('cuda', device)
+        self.anchors = np.asarray(anchors, np.float32)
+        self.hyper = dict(obj_thresh=obj_thresh, iou_thresh=iou_thresh, obj_weight=obj_weight, noobj_weight=noobj_weight,
+                          wh_weight=wh_weight)
+        self.lr, self.decay, self.iterations = float(lr), float(decay), 0
+        self.pg, self.world = process_group, int(world_size)
+        self.lay = {l.name: l for l in spec.layers}
+        self.L = engine.lib()
+
+        # ---- flat parameter / gradient / Adam buffers; conv kernels as [Cout][kh*kw*Cin], depthwise as [9][C]
+        self.slots: Dict[str, tuple] = {}
+        off = 0
+        for l in spec.layers:
+            kh, kw, ci, co = l.kernel_shape
+            shape = (co, kh * kw * ci) if l.kind == 'conv' else (9, ci)
+            items = [(l.name + '/kernel', shape)]
+            if l.use_bias:
+                items.append((l.name + '/bias', (co,)))
+            if l.bn_name:
+                c = co if l.kind == 'conv' else ci
+                items += [(l.bn_name + '/gamma', (c,)), (l.bn_name + '/beta', (c,))]
+            for nm, shp in items:
+                n = int(np.prod(shp))
+                self.slots[nm] = (off, shp)
+                off += (n + 7) // 8 * 8
+        self.n_params = off
+        self.P = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.G = torch.zeros_like(self.P)
+        self.m = torch.zeros_like(self.P)
+        self.v = torch.zeros_like(self.P)
+        self.moving: Dict[str, "torch.Tensor"] = {}
+        self.load_weights(weights)
+        self.counts = [torch.zeros(3, dtype=torch.float32, device=self.dev) for _ in spec.outputs]
+        self.saved: Dict[int, dict] = {}
+        self.T: Dict[int, "torch.Tensor"] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, buf, name):
+        off, shp = self.slots[name]
+        return buf[off:off + int(np.prod(shp))].view(*shp)
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        torch = self.torch
+        for l in self.spec.layers:
+            k = np.asarray(weights[l.name + '/kernel'], np.float32)
+            if l.kind == 'conv':
+                k = np.transpose(k, (3, 0, 1, 2)).reshape(l.kernel_shape[3], -1)          # HWIO -> O,(HWI)
+            else:
+                k = k[..., 0].reshape(9, -1)
+            self.view(self.P, l.name + '/kernel').copy_(torch.from_numpy(np.ascontiguousarray(k)))
+            if l.use_bias:
+                self.view(self.P, l.name + '/bias').copy_(torch.from_numpy(np.asarray(weights[l.name + '/bias'], np.float32)))
+            if l.bn_name:
+                for s in ('/gamma', '/beta'):
+                    self.view(self.P, l.bn_name + s).copy_(torch.from_numpy(np.asarray(weights[l.bn_name + s], np.float32)))
+                for s in ('/moving_mean', '/moving_variance'):
+                    self.moving[l.bn_name + s] = torch.from_numpy(np.asarray(weights[l.bn_name + s], np.float32).copy()).to(self.dev)
+
+    def export_weights(self) -> Dict[str, np.ndarray]:
+        """Keras-layout arrays again (what keras.models.save_model would hold, keras_train.py:107)."""
+        out = {}
+        for l in self.spec.layers:
+            kh, kw, ci, co = l.kernel_shape
+            k = self.view(self.P, l.name + '/kernel').cpu().numpy()
+            out[l.name + '/kernel'] = (np.transpose(k.reshape(co, kh, kw, ci), (1, 2, 3, 0)) if l.kind == 'conv'
+                                       else k.reshape(3, 3, ci)[..., None]).copy()
+            if l.use_bias:
+                out[l.name + '/bias'] = self.view(self.P, l.name + '/bias').cpu().numpy().copy()
+            if l.bn_name:
+                for s in ('/gamma', '/beta'):
+                    out[l.bn_name + s] = self.view(self.P, l.bn_name + s).cpu().numpy().copy()
+                for s in ('/moving_mean', '/moving_variance'):
+                    out[l.bn_name + s] = self.moving[l.bn_name + s].cpu().numpy().copy()
+        return out
+
+    def grads(self) -> Dict[str, np.ndarray]:
+        """Gradients of the last step in Keras layout (for parity tests)."""
+        out = {}
+        for nm, (off, shp) in self.slots.items():
+            g = self.G[off:off + int(np.prod(shp))].view(*shp).cpu().numpy()
+            if nm.endswith('/kernel'):
+                l = self.lay[nm[:-7]]
+                kh, kw, ci, co = l.kernel_shape
+                g = np.transpose(g.reshape(co, kh, kw, ci), (1, 2, 3, 0)) if l.kind == 'conv' else g.reshape(3, 3, ci)[..., None]
+            out[nm] = g.copy()
+        return out
+
+    # ------------------------------------------------------------------ kernel calls
+    def _s(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def _ck(self, rc, what):
+        engine._check(rc, what)
+
+    def _new(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device=self.dev)
+
+    def gemm(self, tA, tB, M, N, K, A, lda, Bm, ldb, Cm, ldc, alpha=1.0, beta=0.0):
+        self._ck(self.L.yk_gemm_f32(C.c_int(tA), C.c_int(tB), C.c_int(M), C.c_int(N), C.c_int(K), C.c_float(alpha), engine._ptr(A),
+                                    C.c_int(lda), engine._ptr(Bm), C.c_int(ldb), C.c_float(beta), engine._ptr(Cm), C.c_int(ldc),
+                                    self._s()), 'yk_gemm_f32')
+
+    def _geom(self, op):
+        hi, wi, ci = self.spec.tensors[op['in0']]
+        ho, wo, _ = self.spec.tensors[op['out']]
+        return [C.c_int(v) for v in (self.B, hi, wi, ci, ho, wo, op['stride'], op['pad_t'], op['pad_l'])]
+
+    def _axpy(self, a, x, y):
+        self._ck(self.L.yk_axpy_f32(C.c_longlong(x.numel()), C.c_float(a), engine._ptr(x), engine._ptr(y), self._s()), 'yk_axpy_f32')
+
+    # ------------------------------------------------------------------ forward (training mode)
+    def forward(self, x_nhwc) -> List["torch.Tensor"]:
+        """x_nhwc: cuda fp32 [B,H,W,3] already normalised (Helper._process_img output).  Saves the tape."""
+        torch = self.torch
+        assert x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[:1]) == (self.B,)
+        T, S = {0: x_nhwc.contiguous()}, {}
+        for i, op in enumerate(self.spec.ops):
+            x, t = T[op['in0']], op['type']
+            ho, wo, co = self.spec.tensors[op['out']]
+            M = self.B * ho * wo
+            if t in (ns.OP_CONV, ns.OP_DWCONV):
+                l = self.lay[op['layer']]
+                w = self.view(self.P, l.name + '/kernel')
+                z = self._new(self.B, ho, wo, co)
+                if t == ns.OP_CONV:
+                    ci, k = op['cin'], op['k']
+                    if k == 1 and op['stride'] == 1:
+                        a, kk = x, ci
+                    else:
+                        assert k == 3
+                        a, kk = self._new(M, 9 * ci), 9 * ci
+                        self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(a), self._s()), 'yk_im2col3x3_f32')
+                    self.gemm(0, 1, M, co, kk, a, kk, w, kk, z, co)                      # Z = X * W^T
+                else:
+                    self._ck(self.L.yk_dw3x3_fwd_f32(engine._ptr(x), engine._ptr(w), *self._geom(op), engine._ptr(z), self._s()),
+                             'yk_dw3x3_fwd_f32')
+                if l.bn_name:
+                    y = self._new(self.B, ho, wo, co)
+                    mean, invstd = self._new(co), self._new(co)
+                    self._ck(self.L.yk_bn_train_fwd_f32(
+                        engine._ptr(z), C.c_longlong(M), C.c_int(co), engine._ptr(self.view(self.P, l.bn_name + '/gamma')),
+                        engine._ptr(self.view(self.P, l.bn_name + '/beta')), C.c_float(ns.BN_EPS), C.c_int(op['act']),
+                        C.c_float(op['alpha']), engine._ptr(y), engine._ptr(mean), engine._ptr(invstd),
+                        engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
+                        C.c_float(BN_MOMENTUM), self._s()), 'yk_bn_train_fwd_f32')
+                    S[i] = dict(z=z, mean=mean, invstd=invstd)
+                else:
+                    assert op['act'] == ns.ACT_NONE
+                    if l.use_bias:
+                        self._ck(self.L.yk_bias_add_f32(engine._ptr(z), C.c_longlong(M), C.c_int(co),
+                                                        engine._ptr(self.view(self.P, l.name + '/bias')), self._s()), 'yk_bias_add_f32')
+                    y = z
+            elif t == ns.OP_MAXPOOL:
+                hi, wi, ci = self.spec.tensors[op['in0']]
+                y = self._new(self.B, ho, wo, co)
+                arg = torch.empty((self.B, ho, wo, co), dtype=torch.uint8, device=self.dev)
+                self._ck(self.L.yk_maxpool2_fwd_f32(engine._ptr(x), C.c_int(self.B), C.c_int(hi), C.c_int(wi), C.c_int(ci), C.c_int(ho),
+                                                    C.c_int(wo), C.c_int(op['stride']), engine._ptr(y), engine._ptr(arg), self._s()),
+                         'yk_maxpool2_fwd_f32')
+                S[i] = dict(arg=arg)
+            elif t == ns.OP_UPSAMPLE:                                                   # nearest x2: pure data movement
+                y = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+            elif t == ns.OP_CONCAT:
+                y = torch.cat([x, T[op['in1']]], dim=3)
+            elif t == ns.OP_ADD:
+                y = x.clone()
+                self._axpy(1.0, T[op['in1']], y)
+            else:
+                raise engine.YkError(f'op type {t} not trainable')
+            T[op['out']] = y
+        self.T, self.saved = T, S
+        e = 5 + self.spec.class_num
+        return [T[o].view(self.B, *self.spec.tensors[o][:2], self.spec.anchor_num, e) for o in self.spec.outputs]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, out_grads: Sequence["torch.Tensor"]) -> None:
+        """out_grads[i] = dL/d(output i).  Fills self.G (kernel/bias/gamma/beta gradients; regulariser added by step())."""
+        torch = self.torch
+        self.G.zero_()
+        D: Dict[int, "torch.Tensor"] = {}
+
+        def acc(tid, g, own):
+            if tid == 0:
+                return
+            if tid not in D:
+                D[tid] = g if own else g.clone()
+            else:
+                self._axpy(1.0, g, D[tid])
+
+        for o, g in zip(self.spec.outputs, out_grads):
+            acc(o, g.reshape(self.B, *self.spec.tensors[o]).contiguous(), False)
+        for i in range(len(self.spec.ops) - 1, -1, -1):
+            op = self.spec.ops[i]
+            t = op['type']
+            dy = D.pop(op['out'], None)
+            if dy is None:
+                continue
+            x = self.T[op['in0']]
+            ho, wo, co = self.spec.tensors[op['out']]
+            hi, wi, ci = self.spec.tensors[op['in0']]
+            M = self.B * ho * wo
+            if t in (ns.OP_CONV, ns.OP_DWCONV):
+                l = self.lay[op['layer']]
+                w = self.view(self.P, l.name + '/kernel')
+                gw = self.view(self.G, l.name + '/kernel')
+                if l.bn_name:
+                    sv = self.saved[i]
+                    dz = self._new(self.B, ho, wo, co)
+                    self._ck(self.L.yk_bn_train_bwd_f32(
+                        engine._ptr(sv['z']), engine._ptr(dy), C.c_longlong(M), C.c_int(co),
+                        engine._ptr(self.view(self.P, l.bn_name + '/gamma')), engine._ptr(self.view(self.P, l.bn_name + '/beta')),
+                        engine._ptr(sv['mean']), engine._ptr(sv['invstd']), C.c_int(op['act']), C.c_float(op['alpha']), engine._ptr(dz),
+                        engine._ptr(self.view(self.G, l.bn_name + '/gamma')), engine._ptr(self.view(self.G, l.bn_name + '/beta')),
+                        self._s()), 'yk_bn_train_bwd_f32')
+                else:
+                    dz = dy
+                    if l.use_bias:
+                        self._ck(self.L.yk_colsum_f32(engine._ptr(dz), C.c_longlong(M), C.c_int(co),
+                                                      engine._ptr(self.view(self.G, l.name + '/bias')), self._s()), 'yk_colsum_f32')
+                need_dx = op['in0'] != 0
+                if t == ns.OP_CONV:
+                    k = op['k']
+                    if k == 1 and op['stride'] == 1:
+                        self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci)               # dW = dZ^T * X
+                        if need_dx:
+                            dx = self._new(self.B, hi, wi, ci)
+                            self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)           # dX = dZ * W
+                            acc(op['in0'], dx, True)
+                    else:
+                        kk = 9 * ci
+                        col = self._new(M, kk)
+                        self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(col), self._s()), 'yk_im2col3x3_f32')
+                        self.gemm(1, 0, co, kk, M, dz, co, col, kk, gw, kk)
+                        if need_dx:
+                            self.gemm(0, 0, M, kk, co, dz, co, w, kk, col, kk)          # dcol (reuses the buffer)
+                            dx = self._new(self.B, hi, wi, ci)
+                            self._ck(self.L.yk_col2im3x3_f32(engine._ptr(col), *self._geom(op), engine._ptr(dx), self._s()),
+                                     'yk_col2im3x3_f32')
+                            acc(op['in0'], dx, True)
+                        del col
+                else:
+                    self._ck(self.L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dz), *self._geom(op), engine._ptr(gw), self._s()),
+                             'yk_dw3x3_bwd_weight_f32')
+                    if need_dx:
+                        dx = self._new(self.B, hi, wi, ci)
+                        self._ck(self.L.yk_dw3x3_bwd_data_f32(engine._ptr(dz), engine._ptr(w), *self._geom(op), engine._ptr(dx), self._s()),
+                                 'yk_dw3x3_bwd_data_f32')
+                        acc(op['in0'], dx, True)
+            elif t == ns.OP_MAXPOOL:
+                dx = self._new(self.B, hi, wi, ci)
+                self._ck(self.L.yk_maxpool2_bwd_f32(engine._ptr(dy), engine._ptr(self.saved[i]['arg']), C.c_int(self.B), C.c_int(hi),
+                                                    C.c_int(wi), C.c_int(ci), C.c_int(ho), C.c_int(wo), C.c_int(op['stride']),
+                                                    engine._ptr(dx), self._s()), 'yk_maxpool2_bwd_f32')
+                acc(op['in0'], dx, True)
+            elif t == ns.OP_UPSAMPLE:
+                dx = self._new(self.B, hi, wi, ci)
+                self._ck(self.L.yk_upsample2x_bwd_f32(engine._ptr(dy), C.c_int(self.B), C.c_int(hi), C.c_int(wi), C.c_int(ci),
+                                                      engine._ptr(dx), self._s()), 'yk_upsample2x_bwd_f32')
+                acc(op['in0'], dx, True)
+            elif t == ns.OP_CONCAT:
+                c0 = self.spec.tensors[op['in0']][2]
+                acc(op['in0'], dy[..., :c0].contiguous(), True)
+                acc(op['in1'], dy[..., c0:].contiguous(), True)
+            elif t == ns.OP_ADD:
+                acc(op['in0'], dy, False)
+                acc(op['in1'], dy, True)
+
+    # ------------------------------------------------------------------ one optimisation step
+    def regulariser(self, add_grad: bool) -> "torch.Tensor":
+        """sum over DarknetConv2D kernels of 5e-4 * sum(w^2) (device scalar); optionally G += 2*5e-4*W."""
+        tot = self.torch.zeros(1, dtype=self.torch.float32, device=self.dev)
+        for l in self.spec.layers:
+            if l.kind == 'conv' and _is_darknet_conv(l.name):
+                w = self.view(self.P, l.name + '/kernel')
+                n = w.numel()
+                self.gemm(0, 1, 1, 1, n, w, n, w, n, tot, 1, alpha=L2_WEIGHT, beta=1.0)   # tot += 5e-4 * <w, w>
+                if add_grad:
+                    self._axpy(2.0 * L2_WEIGHT, w, self.view(self.G, l.name + '/kernel'))
+        return tot
+
+    def loss_and_grads(self, x_nhwc, y_true: Sequence["torch.Tensor"]):
+        """forward + loss + backward (no all-reduce, no update).  -> dict of device scalars."""
+        global_batch = self.B * self.world
+        preds = self.forward(x_nhwc)
+        parts, grads = [], []
+        for li, (yp, yt) in enumerate(zip(preds, y_true)):
+            loss6, g, _ = engine.yolo_loss(yt, yp.contiguous(), self.anchors[li], batch_size=global_batch, counts=self.counts[li],
+                                           **self.hyper)
+            parts.append(loss6)
+            grads.append(g)
+        self.backward(grads)
+        reg = self.regulariser(add_grad=self.world == 1)
+        return dict(layers=parts, reg=reg)
+
+    def step(self, x_nhwc, y_true: Sequence["torch.Tensor"]) -> Dict[str, float]:
+        """model.fit's inner step (keras_train.py:94).  Returns python floats (one device->host sync)."""
+        torch = self.torch
+        r = self.loss_and_grads(x_nhwc, y_true)
+        if self.world > 1:
+            import torch.distributed as dist
+            # data-term gradients already carry 1/global_batch, so SUM over ranks is the global-batch gradient;
+            # the regulariser's gradient is identical on every rank and is added once, after the reduction
+            dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.pg)
+            self.regulariser(add_grad=True)
+        self._ck(self.L.yk_adam_f32(C.c_longlong(self.n_params), engine._ptr(self.P), engine._ptr(self.G), engine._ptr(self.m),
+                                    engine._ptr(self.v), C.c_float(self.lr), C.c_float(self.decay), C.c_longlong(self.iterations),
+                                    C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), self._s()), 'yk_adam_f32')
+        self.iterations += 1
+        data = torch.stack([p[0] for p in r['layers']]).sum()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.pg)
+        vals = torch.cat([data.view(1), r['reg'].view(1)]).cpu().numpy()
+        return dict(loss=float(vals[0] + vals[1]), data_loss=float(vals[0]), reg_loss=float(vals[1]))
+
+    def precision_recall(self):
+        """Yolo_Precision / Yolo_Recall running values per output layer (tools/custom.py:42-44,74-75)."""
+        out = []
+        for c in self.counts:
+            tp, fp, fn = c.cpu().numpy().tolist()
+            out.append((tp / (tp + fp) if tp + fp else 0.0, tp / (tp + fn) if tp + fn else 0.0))
+        return out

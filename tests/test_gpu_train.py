@@ -1,0 +1,283 @@
+"""GPU parity of the training step against oracle/train_ref.py (torch-CPU float64 autograd).
+
+Tolerances (fp32 HIP vs float64 reference): kernels 1e-4 relative to the tensor's max magnitude (fp32 sums over up to
+1e5 terms); whole-step gradients 2e-3 of each tensor's max (≈60 layers of fp32 BatchNorm/ReLU chains); loss 1e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from k210_yolo_framework_amd import netspec as ns
+from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS
+from oracle import train_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from k210_yolo_framework_amd import engine
+    engine.require_gpu()
+    return engine, engine.lib()
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _close(got, ref, tol=1e-4):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref).max()
+    assert err <= tol * max(1e-6, np.abs(ref).max()), (err, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('tA,tB,M,N,K', [(0, 1, 300, 75, 96), (0, 0, 257, 130, 65), (1, 0, 48, 33, 20000), (1, 1, 17, 19, 23),
+                                        (0, 1, 1, 1, 300000), (0, 1, 4480, 96, 16)])
+def test_gemm_all_layouts_and_split_k(tA, tB, M, N, K):
+    engine, L = _lib()
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+    Bm = rng.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    ref = 0.5 * ((A.T if tA else A).astype(np.float64) @ (Bm.T if tB else Bm).astype(np.float64)) + 2.0 * C0
+    a, b, c = _cu(A), _cu(Bm), _cu(C0)
+    assert L.yk_gemm_f32(tA, tB, M, N, K, C.c_float(0.5), engine._ptr(a), A.shape[1], engine._ptr(b), Bm.shape[1], C.c_float(2.0),
+                         engine._ptr(c), N, _st()) == 0
+    _close(c.cpu().numpy(), ref, 2e-5)
+
+
+@pytest.mark.parametrize('stride,pad', [(1, (1, 1)), (2, (1, 1)), (2, (1, 0))])
+def test_conv3x3_im2col_gemm_and_adjoint(stride, pad):
+    engine, L = _lib()
+    rng = np.random.default_rng(stride)
+    B, Hi, Wi, Ci, Co = 3, 13, 18, 7, 10
+    pt, pl = pad[0], pad[0]
+    pb = pr = pad[1]
+    Ho, Wo = (Hi + pt + pb - 3) // stride + 1, (Wi + pl + pr - 3) // stride + 1
+    x = rng.normal(size=(B, Hi, Wi, Ci)).astype(np.float32)
+    w = rng.normal(size=(3, 3, Ci, Co)).astype(np.float32)
+    dy = rng.normal(size=(B, Ho, Wo, Co)).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    yt = F.conv2d(F.pad(xt, (pl, pr, pt, pb)), wt.permute(3, 2, 0, 1), stride=stride)
+    yt.backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    M, KK = B * Ho * Wo, 9 * Ci
+    geom = [C.c_int(v) for v in (B, Hi, Wi, Ci, Ho, Wo, stride, pt, pl)]
+    xd, dyd = _cu(x), _cu(dy)
+    wd = _cu(np.transpose(w, (3, 0, 1, 2)).reshape(Co, KK))
+    col = torch.empty(M, KK, device='cuda')
+    assert L.yk_im2col3x3_f32(engine._ptr(xd), *geom, engine._ptr(col), _st()) == 0
+    y = torch.empty(M, Co, device='cuda')
+    assert L.yk_gemm_f32(0, 1, M, Co, KK, C.c_float(1), engine._ptr(col), KK, engine._ptr(wd), KK, C.c_float(0), engine._ptr(y), Co, _st()) == 0
+    _close(y.cpu().numpy().reshape(B, Ho, Wo, Co), yt.detach().permute(0, 2, 3, 1).numpy())
+    gw = torch.empty(Co, KK, device='cuda')
+    assert L.yk_gemm_f32(1, 0, Co, KK, M, C.c_float(1), engine._ptr(dyd), Co, engine._ptr(col), KK, C.c_float(0), engine._ptr(gw), KK, _st()) == 0
+    _close(np.transpose(gw.cpu().numpy().reshape(Co, 3, 3, Ci), (1, 2, 3, 0)), wt.grad.numpy())
+    assert L.yk_gemm_f32(0, 0, M, KK, Co, C.c_float(1), engine._ptr(dyd), Co, engine._ptr(wd), KK, C.c_float(0), engine._ptr(col), KK, _st()) == 0
+    dx = torch.empty(B, Hi, Wi, Ci, device='cuda')
+    assert L.yk_col2im3x3_f32(engine._ptr(col), *geom, engine._ptr(dx), _st()) == 0
+    _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_depthwise_forward_and_both_gradients(stride):
+    engine, L = _lib()
+    rng = np.random.default_rng(10 + stride)
+    B, Hi, Wi, Cc = 4, 15, 22, 72
+    Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+    x = rng.normal(size=(B, Hi, Wi, Cc)).astype(np.float32)
+    w = rng.normal(size=(3, 3, Cc)).astype(np.float32)
+    dy = rng.normal(size=(B, Ho, Wo, Cc)).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    yt = F.conv2d(F.pad(xt, (1, 1, 1, 1)), wt.permute(2, 0, 1)[:, None], stride=stride, groups=Cc)
+    yt.backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    geom = [C.c_int(v) for v in (B, Hi, Wi, Cc, Ho, Wo, stride, 1, 1)]
+    xd, wd, dyd = _cu(x), _cu(w.reshape(9, Cc)), _cu(dy)
+    y, dx, dw = torch.empty(B, Ho, Wo, Cc, device='cuda'), torch.empty(B, Hi, Wi, Cc, device='cuda'), torch.empty(9, Cc, device='cuda')
+    assert L.yk_dw3x3_fwd_f32(engine._ptr(xd), engine._ptr(wd), *geom, engine._ptr(y), _st()) == 0
+    assert L.yk_dw3x3_bwd_data_f32(engine._ptr(dyd), engine._ptr(wd), *geom, engine._ptr(dx), _st()) == 0
+    assert L.yk_dw3x3_bwd_weight_f32(engine._ptr(xd), engine._ptr(dyd), *geom, engine._ptr(dw), _st()) == 0
+    _close(y.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy())
+    _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+    _close(dw.cpu().numpy().reshape(3, 3, Cc), wt.grad.numpy())
+
+
+@pytest.mark.parametrize('act,alpha,M,Cc', [(ns.ACT_NONE, 0.0, 1000, 24), (ns.ACT_RELU, 0.0, 4097, 96), (ns.ACT_RELU6, 6.0, 700, 130),
+                                           (ns.ACT_LEAKY, 0.1, 70, 75), (ns.ACT_LEAKY, 0.3, 200000, 16)])
+def test_batchnorm_training_forward_backward(act, alpha, M, Cc):
+    engine, L = _lib()
+    rng = np.random.default_rng(M)
+    z = (rng.normal(size=(M, Cc)) * rng.uniform(0.5, 3, Cc) + rng.normal(size=Cc) * 2).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 3, Cc).astype(np.float32), rng.normal(size=Cc).astype(np.float32)
+    dy = rng.normal(size=(M, Cc)).astype(np.float32)
+    zt = torch.from_numpy(z).double().requires_grad_(True)
+    gt, bt = torch.from_numpy(gamma).double().requires_grad_(True), torch.from_numpy(beta).double().requires_grad_(True)
+    mu, var = zt.mean(0), ((zt - zt.mean(0)) ** 2).mean(0)
+    yt = (zt - mu) / torch.sqrt(var + 1e-3) * gt + bt
+    yt = {ns.ACT_NONE: lambda v: v, ns.ACT_RELU: F.relu, ns.ACT_RELU6: lambda v: v.clamp(0, 6),
+          ns.ACT_LEAKY: lambda v: F.leaky_relu(v, alpha)}[act](yt)
+    yt.backward(torch.from_numpy(dy).double())
+    zd, gd, bd, dyd = _cu(z), _cu(gamma), _cu(beta), _cu(dy)
+    y, dz = torch.empty(M, Cc, device='cuda'), torch.empty(M, Cc, device='cuda')
+    sm, si, dg, db = (torch.empty(Cc, device='cuda') for _ in range(4))
+    mm, mv = torch.zeros(Cc, device='cuda'), torch.ones(Cc, device='cuda')
+    assert L.yk_bn_train_fwd_f32(engine._ptr(zd), C.c_longlong(M), Cc, engine._ptr(gd), engine._ptr(bd), C.c_float(1e-3), act, C.c_float(alpha),
+                                 engine._ptr(y), engine._ptr(sm), engine._ptr(si), engine._ptr(mm), engine._ptr(mv), C.c_float(0.99), _st()) == 0
+    assert L.yk_bn_train_bwd_f32(engine._ptr(zd), engine._ptr(dyd), C.c_longlong(M), Cc, engine._ptr(gd), engine._ptr(bd), engine._ptr(sm),
+                                 engine._ptr(si), act, C.c_float(alpha), engine._ptr(dz), engine._ptr(dg), engine._ptr(db), _st()) == 0
+    _close(sm.cpu().numpy(), mu.detach().numpy(), 1e-5)
+    _close(si.cpu().numpy(), (1 / torch.sqrt(var + 1e-3)).detach().numpy(), 1e-5)
+    _close(mm.cpu().numpy(), 0.01 * mu.detach().numpy(), 1e-5)
+    _close(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy(), 1e-5)
+    # activation kinks: an fp32 pre-activation within rounding of 0/6 may land on the other side — exclude those elements
+    pre = ((zt - mu) / torch.sqrt(var + 1e-3) * gt + bt).detach().numpy()
+    safe = (np.abs(pre) > 1e-4) & (np.abs(pre - 6) > 1e-4)
+    got_y, got_dz = y.cpu().numpy(), dz.cpu().numpy()
+    assert np.abs(got_y - yt.detach().numpy()).max() <= 2e-5 * np.abs(pre).max()
+    if safe.all():
+        _close(got_dz, zt.grad.numpy(), 2e-4)
+        _close(dg.cpu().numpy(), gt.grad.numpy(), 2e-4)
+        _close(db.cpu().numpy(), bt.grad.numpy(), 2e-4)
+    else:                                     # a flipped kink element changes the column sums slightly
+        assert np.abs(got_dz - zt.grad.numpy())[safe].max() <= 5e-3 * np.abs(zt.grad.numpy()).max()
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_maxpool_upsample_bias_colsum_axpy(stride):
+    engine, L = _lib()
+    rng = np.random.default_rng(stride)
+    B, Hi, Wi, Cc = 2, 13, 20, 16
+    Ho, Wo = -(-Hi // stride), -(-Wi // stride)
+    x = rng.normal(size=(B, Hi, Wi, Cc)).astype(np.float32)
+    dy = rng.normal(size=(B, Ho, Wo, Cc)).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    pb, pr = max((Ho - 1) * stride + 2 - Hi, 0), max((Wo - 1) * stride + 2 - Wi, 0)
+    yt = F.max_pool2d(F.pad(xt, (0, pr, 0, pb), value=float('-inf')), 2, stride)
+    yt.backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    xd, dyd = _cu(x), _cu(dy)
+    y, dx = torch.empty(B, Ho, Wo, Cc, device='cuda'), torch.empty(B, Hi, Wi, Cc, device='cuda')
+    arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device='cuda')
+    assert L.yk_maxpool2_fwd_f32(engine._ptr(xd), B, Hi, Wi, Cc, Ho, Wo, stride, engine._ptr(y), engine._ptr(arg), _st()) == 0
+    assert L.yk_maxpool2_bwd_f32(engine._ptr(dyd), engine._ptr(arg), B, Hi, Wi, Cc, Ho, Wo, stride, engine._ptr(dx), _st()) == 0
+    assert np.array_equal(y.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).float().numpy())
+    _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), 1e-6)
+    # UpSampling2D(2) adjoint
+    g = rng.normal(size=(B, 2 * Hi, 2 * Wi, Cc)).astype(np.float32)
+    gd, du = _cu(g), torch.empty(B, Hi, Wi, Cc, device='cuda')
+    assert L.yk_upsample2x_bwd_f32(engine._ptr(gd), B, Hi, Wi, Cc, engine._ptr(du), _st()) == 0
+    _close(du.cpu().numpy(), g.reshape(B, Hi, 2, Wi, 2, Cc).astype(np.float64).sum((2, 4)), 1e-6)
+    # bias / column sum / axpy
+    bias = rng.normal(size=Cc).astype(np.float32)
+    yb, cs = _cu(x), torch.empty(Cc, device='cuda')
+    assert L.yk_bias_add_f32(engine._ptr(yb), C.c_longlong(B * Hi * Wi), Cc, engine._ptr(_cu(bias)), _st()) == 0
+    assert np.array_equal(yb.cpu().numpy(), x + bias)
+    assert L.yk_colsum_f32(engine._ptr(xd), C.c_longlong(B * Hi * Wi), Cc, engine._ptr(cs), _st()) == 0
+    _close(cs.cpu().numpy(), x.reshape(-1, Cc).astype(np.float64).sum(0), 1e-5)
+    assert L.yk_axpy_f32(C.c_longlong(x.size), C.c_float(-0.25), engine._ptr(xd), engine._ptr(yb), _st()) == 0
+    _close(yb.cpu().numpy(), (x + bias) - 0.25 * x, 1e-6)
+
+
+def test_adam_matches_keras_update_rule_with_decay():
+    engine, L = _lib()
+    rng = np.random.default_rng(0)
+    n = 10007
+    p0 = rng.normal(size=n).astype(np.float32)
+    ref = train_ref.AdamRef(5e-4, decay=0.01)
+    w = {'p': p0.astype(np.float64)}
+    p, m, v = _cu(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for it in range(4):
+        g = (rng.normal(size=n) * 10.0 ** rng.integers(-4, 2, n)).astype(np.float32)
+        w = ref.apply(w, {'p': g.astype(np.float64)})
+        assert L.yk_adam_f32(C.c_longlong(n), engine._ptr(p), engine._ptr(_cu(g)), engine._ptr(m), engine._ptr(v), C.c_float(5e-4),
+                             C.c_float(0.01), C.c_longlong(it), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), _st()) == 0
+        assert np.abs(p.cpu().numpy() - w['p']).max() <= 2e-6
+
+
+# --------------------------------------------------------------------------------------------- whole step
+def _case(name, hw, B, alpha, seed):
+    spec = ns.NETWORKS[name]([hw[0], hw[1], 3], 3, 20, alpha=alpha)
+    w = spec.init_weights(seed)
+    h = Helper(None, 20, VOC_ANCHORS if len(spec.outputs) == 2 else np.concatenate([VOC_ANCHORS, VOC_ANCHORS[:1] * 0.5]),
+               [list(hw)], [list(x) for x in spec.out_hw()])
+    rng = np.random.default_rng(seed)
+    ys = [[] for _ in spec.outputs]
+    for b in range(B):
+        n = int(rng.integers(1, 5))
+        boxes = np.stack([rng.integers(0, 20, n), rng.uniform(.2, .8, n), rng.uniform(.2, .8, n), rng.uniform(.1, .6, n), rng.uniform(.1, .6, n)], 1)
+        for i, lab in enumerate(h.box_to_label(boxes)):
+            ys[i].append(lab)
+    yt = [np.stack(y).astype(np.float32) for y in ys]
+    x = rng.uniform(0, 1, (B, hw[0], hw[1], 3)).astype(np.float32)
+    return spec, w, h, x, yt
+
+
+@pytest.mark.parametrize('name,hw,B,alpha', [('yolo_mobilev1', (64, 96), 4, 0.5), ('yolo_mobilev2', (64, 96), 4, 0.5),
+                                            ('tiny_yolo', (64, 96), 3, 1.0), ('yolo', (64, 64), 2, 1.0)])
+def test_training_step_loss_gradients_and_adam_update_vs_autograd(name, hw, B, alpha):
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case(name, hw, B, alpha, 5)
+    hyper = dict(obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0)
+    ref_data, ref_reg, ref_g, ref_stats, ref_pred = train_ref.loss_and_grads(spec, w, x, yt, h.anchors, **hyper)
+    tr = Trainer(spec, w, h.anchors, B, lr=5e-4, decay=0.0, **hyper)
+    out = tr.step(_cu(x), [_cu(y) for y in yt])
+    torch.cuda.synchronize()
+    assert abs(out['data_loss'] - ref_data) <= 1e-4 * abs(ref_data), (out, ref_data)
+    assert abs(out['reg_loss'] - ref_reg) <= 1e-5 * abs(ref_reg), (out, ref_reg)
+    got = tr.grads()
+    worst = 0.0
+    gmax = max(np.abs(v).max() for v in ref_g.values())
+    for k, rg in ref_g.items():
+        # floor: a BN beta feeding straight into another BatchNorm has an analytically ZERO gradient (fp32 leaves rounding noise)
+        scale = max(np.abs(rg).max(), 1e-5 * gmax)
+        e = np.abs(got[k] - rg).max() / scale
+        worst = max(worst, e)
+        assert e <= 2e-3, (k, e, scale)
+    print(name, 'worst gradient error (relative to tensor max):', worst)
+
+
+def test_adam_step_moves_weights_like_reference_and_loss_decreases():
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case('yolo_mobilev1', (64, 96), 4, 0.5, 9)
+    hyper = dict(obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0)
+    tr = Trainer(spec, w, h.anchors, 4, lr=1e-3, decay=0.0, **hyper)
+    xd, ytd = _cu(x), [_cu(y) for y in yt]
+    ref_opt, wref = train_ref.AdamRef(1e-3), {k: np.asarray(v, np.float64) for k, v in w.items()}
+    losses = []
+    for it in range(3):
+        _, _, g, stats, _ = train_ref.loss_and_grads(spec, wref, x, yt, h.anchors, **hyper)
+        wref = ref_opt.apply(wref, g)
+        losses.append(tr.step(xd, ytd)['loss'])
+        got = tr.export_weights()
+        for k in g:
+            # Adam's first steps are ~lr*sign(g): where |g| is at rounding level the sign is arbitrary, so bound by a fraction of
+            # the step size on average and by the step size itself everywhere
+            d = np.abs(got[k] - wref[k])
+            assert d.max() <= 2.5e-3 * (it + 1), (k, it, d.max())
+            assert d.mean() <= 1e-4 * (it + 1), (k, it, d.mean())
+    for k in range(8):
+        losses.append(tr.step(xd, ytd)['loss'])
+    assert losses[-1] < 0.7 * losses[0], losses                    # overfits one batch
+    mm = tr.export_weights()['conv1_bn/moving_mean']
+    assert np.isfinite(mm).all() and not np.allclose(mm, w['conv1_bn/moving_mean'])
+    pr = tr.precision_recall()
+    assert len(pr) == 2 and all(0.0 <= v <= 1.0 for t in pr for v in t)
+
+
+def test_moving_statistics_follow_keras_momentum_rule():
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case('yolo_mobilev1', (64, 96), 4, 0.5, 11)
+    _, _, _, stats, preds = train_ref.loss_and_grads(spec, w, x, yt, h.anchors)
+    tr = Trainer(spec, w, h.anchors, 4)
+    got_preds = tr.forward(_cu(x))
+    for gp, rp in zip(got_preds, preds):
+        _close(gp.cpu().numpy(), rp, 2e-4)
+    for bn, (mu, var) in stats.items():
+        _close(tr.moving[bn + '/moving_mean'].cpu().numpy(), 0.99 * w[bn + '/moving_mean'] + 0.01 * mu, 1e-4)
+        _close(tr.moving[bn + '/moving_variance'].cpu().numpy(), 0.99 * w[bn + '/moving_variance'] + 0.01 * var, 1e-4)
