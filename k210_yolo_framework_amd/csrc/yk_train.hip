@@ -25,7 +25,7 @@ struct gemm_args {
     int M, N, K, lda, ldb, ldc, transA, transB, splitk;
     float alpha, beta;
     const float *A, *B;
-    float *C;
+    float *C, *ws;
 };
 
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
@@ -86,19 +86,25 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 32 + i * 16 + fq * 4 + r, n = n0 + wn * 32 + j * 16 + fr;
                 if (m < g.M && n < g.N) {
-                    float *c = g.C + (size_t)m * g.ldc + n;
-                    const float v = g.alpha * acc[i][j][r];
-                    if (g.splitk > 1) atomicAdd(c, v);       // C pre-scaled by beta on the host side of the call
-                    else *c = v + (g.beta != 0.f ? g.beta * *c : 0.f);
+                    if (g.splitk > 1) {                      // deterministic split-K: one slab per split, summed in order
+                        g.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                    } else {
+                        float *c = g.C + (size_t)m * g.ldc + n;
+                        *c = g.alpha * acc[i][j][r] + (g.beta != 0.f ? g.beta * *c : 0.f);
+                    }
                 }
             }
 }
 
-__global__ void __launch_bounds__(256) scale_kernel(float *c, size_t rows, int cols, int ld, float beta) {
+__global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict__ ws, int splits, int M, int N, float alpha, float beta,
+                                                         float *__restrict__ c, int ldc) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * (size_t)cols) return;
-    const size_t r = i / cols, q = i - r * cols;
-    c[r * ld + q] = beta == 0.f ? 0.f : c[r * ld + q] * beta;
+    if (i >= (size_t)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * M * N + i];
+    const size_t r = i / N, q = i - r * N;
+    float *o = c + r * ldc + q;
+    *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
 }
 
 extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B,
@@ -119,12 +125,20 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
         if (s > 256) s = 256;
     }
     g.splitk = s;
+    g.ws = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (s > 1) {
-        const size_t tot = (size_t)M * N;
-        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C, (size_t)M, N, ldc, beta);
+        int dev = yk_current_device();
+        if (dev < 0) return YK_ERR_NO_DEVICE;
+        g.ws = (float *)yk_scratch(dev, stream, 14, sizeof(float) * (size_t)s * M * N);
+        if (!g.ws) return YK_ERR_NOMEM;
     }
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((M + 63) / 64, (N + 63) / 64, s), dim3(256), 0, st, g);
+    if (s > 1) {
+        const size_t tot = (size_t)M * N;
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta, C,
+                           ldc);
+    }
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

@@ -34,7 +34,7 @@ def forward_train(spec: ns.NetSpec, params: Dict[str, torch.Tensor], x_nhwc: tor
     """Training-mode forward (batch statistics, biased variance).  params: Keras-layout float64 leaf tensors."""
     lay = {l.name: l for l in spec.layers}
     T = {0: x_nhwc.permute(0, 3, 1, 2)}
-    for op in spec.ops:
+    for idx, op in enumerate(spec.ops):
         x = T[op['in0']]
         t = op['type']
         if t in (ns.OP_CONV, ns.OP_DWCONV):
@@ -57,6 +57,8 @@ def forward_train(spec: ns.NetSpec, params: Dict[str, torch.Tensor], x_nhwc: tor
                     stats[l.bn_name] = (mu.detach().flatten().numpy(), var.detach().flatten().numpy())
                 y = (y - mu) / torch.sqrt(var + ns.BN_EPS) * params[l.bn_name + '/gamma'].view(1, -1, 1, 1) \
                     + params[l.bn_name + '/beta'].view(1, -1, 1, 1)
+                if stats is not None and stats.get('__want_pre__'):
+                    stats[l.name + '/pre'] = y.detach().permute(0, 2, 3, 1).numpy()
             a = op['act']
             if a == ns.ACT_RELU:
                 y = F.relu(y)
@@ -70,6 +72,8 @@ def forward_train(spec: ns.NetSpec, params: Dict[str, torch.Tensor], x_nhwc: tor
             pb = max((ho - 1) * st + 2 - x.shape[2], 0)
             pr = max((wo - 1) * st + 2 - x.shape[3], 0)
             y = F.max_pool2d(F.pad(x, (0, pr, 0, pb), value=float('-inf')), 2, st)
+            if stats is not None and stats.get('__want_pre__'):
+                stats[f'op{idx}/pool_in'] = x.detach().permute(0, 2, 3, 1).numpy()
         elif t == ns.OP_UPSAMPLE:
             y = F.interpolate(x, scale_factor=2, mode='nearest')
         elif t == ns.OP_CONCAT:
@@ -119,18 +123,19 @@ def yolo_loss_torch(yt, yp, anchors, obj_thresh, iou_thresh, ow, nw, ww, batch_s
 
 
 def loss_and_grads(spec: ns.NetSpec, weights: Dict[str, np.ndarray], x_nhwc: np.ndarray, y_true: Sequence[np.ndarray], anchors,
-                   obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0, batch_size=None):
+                   obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0, batch_size=None, want_pre=False):
     """-> (data_loss, reg_loss, grads dict in Keras layout, bn batch stats)."""
     trainable = [k for k in weights if not k.endswith(('/moving_mean', '/moving_variance'))]
     params = {k: torch.from_numpy(np.asarray(weights[k], np.float64)).requires_grad_(True) for k in trainable}
     x = torch.from_numpy(np.asarray(x_nhwc, np.float64))
-    stats = {}
+    stats = {'__want_pre__': True} if want_pre else {}
     preds = forward_train(spec, params, x, stats)
     bs = batch_size if batch_size else x.shape[0]
     data = sum(yolo_loss_torch(torch.from_numpy(np.asarray(yt, np.float64)), yp, anchors[i], obj_thresh, iou_thresh, obj_weight,
                                noobj_weight, wh_weight, bs) for i, (yt, yp) in enumerate(zip(y_true, preds)))
     reg = sum(L2_WEIGHT * (params[l.name + '/kernel'] ** 2).sum() for l in spec.layers if l.kind == 'conv' and _is_darknet_conv(l.name))
     (data + reg).backward()
+    stats.pop('__want_pre__', None)
     grads = {k: (p.grad.numpy() if p.grad is not None else np.zeros(p.shape)) for k, p in params.items()}
     return float(data.detach()), float(reg.detach()), grads, stats, [p.detach().numpy() for p in preds]
 

@@ -218,28 +218,71 @@ def _case(name, hw, B, alpha, seed):
     return spec, w, h, x, yt
 
 
+def _gate_flips(tr, spec, stats):
+    """Elements whose activation gate (ReLU/ReLU6/LeakyReLU kink) is evaluated on different sides by the fp32 tape and the float64
+    oracle.  There the two compute different — equally valid — sub-gradients, and with batch-statistics BatchNorm over a few
+    dozen samples one flipped element moves every upstream gradient by ~1e-2, so the comparison is only defined for flips == 0."""
+    flips = 0
+    for i, op in enumerate(spec.ops):
+        if op['type'] == ns.OP_MAXPOOL:                    # the winning tap of a 2x2 window is a gate too
+            xin = stats[f'op{i}/pool_in']
+            arg = tr.saved[i]['arg'].cpu().numpy()
+            Bq, Ho, Wo, Cc = arg.shape
+            st = op['stride']
+            pad = np.full((Bq, (Ho - 1) * st + 2, (Wo - 1) * st + 2, Cc), -np.inf)
+            pad[:, :xin.shape[1], :xin.shape[2]] = xin
+            taps = np.stack([pad[:, (t >> 1):(t >> 1) + (Ho - 1) * st + 1:st, (t & 1):(t & 1) + (Wo - 1) * st + 1:st] for t in range(4)], -1)
+            flips += int((taps.argmax(-1) != arg).sum())
+            continue
+        if i not in tr.saved or 'z' not in tr.saved[i] or op['act'] == ns.ACT_NONE:
+            continue
+        l = tr.lay[op['layer']]
+        sv = tr.saved[i]
+        pre = ((sv['z'] - sv['mean']) * sv['invstd'] * tr.view(tr.P, l.bn_name + '/gamma') + tr.view(tr.P, l.bn_name + '/beta')).cpu().numpy()
+        rp = stats[l.name + '/pre']
+        flips += int(((pre > 0) != (rp > 0)).sum())
+        if op['act'] == ns.ACT_RELU6:
+            flips += int(((pre < 6) != (rp < 6)).sum())
+    return flips
+
+
 @pytest.mark.parametrize('name,hw,B,alpha', [('yolo_mobilev1', (64, 96), 4, 0.5), ('yolo_mobilev2', (64, 96), 4, 0.5),
                                             ('tiny_yolo', (64, 96), 3, 1.0), ('yolo', (64, 64), 2, 1.0)])
-def test_training_step_loss_gradients_and_adam_update_vs_autograd(name, hw, B, alpha):
+def test_training_step_loss_and_all_gradients_vs_autograd(name, hw, B, alpha):
     from k210_yolo_framework_amd.train import Trainer
-    spec, w, h, x, yt = _case(name, hw, B, alpha, 5)
     hyper = dict(obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0)
-    ref_data, ref_reg, ref_g, ref_stats, ref_pred = train_ref.loss_and_grads(spec, w, x, yt, h.anchors, **hyper)
-    tr = Trainer(spec, w, h.anchors, B, lr=5e-4, decay=0.0, **hyper)
-    out = tr.step(_cu(x), [_cu(y) for y in yt])
-    torch.cuda.synchronize()
-    assert abs(out['data_loss'] - ref_data) <= 1e-4 * abs(ref_data), (out, ref_data)
-    assert abs(out['reg_loss'] - ref_reg) <= 1e-5 * abs(ref_reg), (out, ref_reg)
-    got = tr.grads()
-    worst = 0.0
-    gmax = max(np.abs(v).max() for v in ref_g.values())
-    for k, rg in ref_g.items():
-        # floor: a BN beta feeding straight into another BatchNorm has an analytically ZERO gradient (fp32 leaves rounding noise)
-        scale = max(np.abs(rg).max(), 1e-5 * gmax)
-        e = np.abs(got[k] - rg).max() / scale
-        worst = max(worst, e)
-        assert e <= 2e-3, (k, e, scale)
-    print(name, 'worst gradient error (relative to tensor max):', worst)
+    compared = 0
+    for seed in range(5, 17):                              # every kernel is deterministic, so this scan is reproducible
+        spec, w, h, x, yt = _case(name, hw, B, alpha, seed)
+        ref_data, ref_reg, ref_g, ref_stats, ref_pred = train_ref.loss_and_grads(spec, w, x, yt, h.anchors, want_pre=True, **hyper)
+        tr = Trainer(spec, w, h.anchors, B, lr=5e-4, decay=0.0, **hyper)
+        r = tr.loss_and_grads(_cu(x), [_cu(y) for y in yt])
+        torch.cuda.synchronize()
+        data = float(sum(p[0] for p in r['layers']).cpu())
+        assert abs(data - ref_data) <= 1e-4 * abs(ref_data), (data, ref_data)          # loss: always comparable
+        assert abs(float(r['reg'].cpu()) - ref_reg) <= 1e-5 * abs(ref_reg)
+        flips = _gate_flips(tr, spec, ref_stats)
+        if flips:
+            print(name, 'seed', seed, 'gate flips', flips, '-> gradients not comparable, next seed')
+            continue
+        got = tr.grads()
+        worst = 0.0
+        gmax = max(np.abs(v).max() for v in ref_g.values())
+        for k, rg in ref_g.items():
+            if np.abs(rg).max() < 1e-9 * gmax:
+                # a BN beta that feeds straight into another BatchNorm has an analytically ZERO gradient; fp32 leaves the
+                # rounding residue of a sum of O(gmax) terms that cancel
+                assert np.abs(got[k]).max() <= 1e-6 * gmax, (k, np.abs(got[k]).max(), gmax)
+                continue
+            scale = np.abs(rg).max()
+            e = np.abs(got[k] - rg).max() / scale
+            worst = max(worst, e)
+            assert e <= 2e-3, (k, e, scale)
+        print(name, 'seed', seed, 'worst gradient error (relative to tensor max):', worst)
+        compared += 1
+        if compared == (1 if name == 'yolo' else 2):
+            break
+    assert compared >= 1, 'no flip-free seed found'
 
 
 def test_adam_step_moves_weights_like_reference_and_loss_decreases():
@@ -281,3 +324,16 @@ def test_moving_statistics_follow_keras_momentum_rule():
     for bn, (mu, var) in stats.items():
         _close(tr.moving[bn + '/moving_mean'].cpu().numpy(), 0.99 * w[bn + '/moving_mean'] + 0.01 * mu, 1e-4)
         _close(tr.moving[bn + '/moving_variance'].cpu().numpy(), 0.99 * w[bn + '/moving_variance'] + 0.01 * var, 1e-4)
+
+
+def test_training_step_is_bitwise_reproducible():
+    """No atomics anywhere in the step (split-K slabs and column sums are reduced in a fixed order)."""
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case('yolo_mobilev2', (64, 96), 4, 0.5, 21)
+    runs = []
+    for _ in range(2):
+        tr = Trainer(spec, w, h.anchors, 4)
+        tr.step(_cu(x), [_cu(y) for y in yt])
+        tr.step(_cu(x), [_cu(y) for y in yt])
+        runs.append((tr.G.cpu().numpy().copy(), tr.P.cpu().numpy().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
