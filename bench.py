@@ -50,6 +50,67 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
                       f'oracle/decode_ref.py, {t_total:.1f} s'}
 
 
+def train_main(args):
+    """BASELINE configs[3]: yolo_mobilev2 alpha=1.0 VOC training step, 16 images per GPU, YOLO loss, one flat RCCL
+    all-reduce of the gradients.  Not the headline metric; same timing contract (barrier + sync, max over ranks)."""
+    import torch
+    from k210_yolo_framework_amd import engine, netspec, shard
+    from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS
+    from k210_yolo_framework_amd.train import Trainer
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    engine.require_gpu()
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+    B = 16 if args.batch == 32 else args.batch
+    spec = netspec.yolo_mobilev2((224, 320, 3), 3, 20, alpha=1.0)
+    weights = spec.init_weights(seed=1)
+    h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [list(x) for x in spec.out_hw()])
+    rng = np.random.default_rng(rank)
+    ys = [[] for _ in spec.outputs]
+    for b in range(B):
+        n = int(rng.integers(1, 6))
+        boxes = np.stack([rng.integers(0, 20, n), rng.uniform(.2, .8, n), rng.uniform(.2, .8, n), rng.uniform(.1, .6, n),
+                          rng.uniform(.1, .6, n)], 1)
+        for i, lab in enumerate(h.box_to_label(boxes)):
+            ys[i].append(lab)
+    y_true = [torch.from_numpy(np.stack(y).astype(np.float32)).cuda() for y in ys]
+    x = torch.from_numpy(rng.uniform(0, 1, (B, 224, 320, 3)).astype(np.float32)).cuda()
+    tr = Trainer(spec, weights, h.anchors, B, lr=5e-4, decay=0.0, device=local, process_group=None, world_size=world)
+    steps, warm = min(args.steps, 50), min(max(args.warmup, 2), 5)
+    for _ in range(warm):
+        last = tr.step(x, y_true)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = tr.step(x, y_true)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        elapsed = shard.max_over_ranks(elapsed, dist, device='cuda')
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training images/sec, yolo_mobilev2-1.0 VOC step b16/GPU', 'value': round(world * B * steps / elapsed, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': warm, 'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[3]: yolo_mobilev2 alpha=1.0, 224x320x3, 20-class VOC head, forward(train-mode BN) + YOLO loss '
+                                   '+ backward + l2 + Adam' + (' + flat RCCL all-reduce' if world > 1 else ''),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'params': int(tr.n_params), 'last_loss': round(last['loss'], 4),
+                       'parallelism': f'data-parallel x{world}'}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -59,7 +120,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay a captured HIP graph instead of launching eagerly '
                     '(measured: no gain, the step is GPU-bound; kept as an option)')
+    ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
+                    help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
     args = ap.parse_args()
+    if args.mode == 'train':
+        return train_main(args)
 
     import torch
     from k210_yolo_framework_amd import engine, netspec

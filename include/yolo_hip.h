@@ -257,6 +257,7 @@ int yk_maxpool2_fwd_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, in
                         void *stream);
 int yk_maxpool2_bwd_f32(const float *dy, const uint8_t *argmax, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *dx,
                         void *stream);
+int yk_dot_f32(long long n, const float *x, const float *y, float alpha, float beta, float *out, void *stream); /* *out = alpha*<x,y> + beta*(*out) */
 int yk_axpy_f32(long long n, float a, const float *x, float *y, void *stream);            /* y += a*x */
 /* keras.optimizers.Adam as keras_train.py:74-76 configures it (lr, decay; beta 0.9/0.999, eps 1e-7):
  * lr_t = lr/(1+decay*iterations) * sqrt(1-b2^t)/(1-b1^t), t = iterations+1; p -= lr_t*m/(sqrt(v)+eps).

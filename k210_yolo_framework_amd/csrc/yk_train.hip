@@ -14,6 +14,7 @@
 #include "yk_common.h"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 typedef float floatx4t __attribute__((ext_vector_type(4)));
 
@@ -29,7 +30,7 @@ struct gemm_args {
 };
 
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
-    constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;
+    constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;       // row stride = 16 mod 32 banks: a 4-row fragment read is conflict-free
     __shared__ float As[BK][LDT], Bs[BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -37,32 +38,40 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
     const int nk = (g.K + BK - 1) / BK;
     const int per = (nk + g.splitk - 1) / g.splitk;
     const int kb = blockIdx.z * per, ke = min(nk, kb + per);
-    floatx4t acc[2][2];
+    floatx4t acc[2][2];                                      // [n tile][m tile]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4t{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = kb; kt < ke; ++kt) {
+    // each thread brings 4 elements of A and 4 of B per k-tile; the index split follows the contiguous axis
+    int a_mm[4], a_kk[4], b_nn[4], b_kk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256;
+        if (g.transA) { a_kk[i] = e >> 6; a_mm[i] = e & 63; } else { a_mm[i] = e >> 4; a_kk[i] = e & 15; }
+        if (g.transB) { b_nn[i] = e >> 4; b_kk[i] = e & 15; } else { b_kk[i] = e >> 6; b_nn[i] = e & 63; }
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int kt) {
         const int k0 = kt * BK;
-        // each thread brings 4 elements of A and 4 of B; the index split follows the contiguous axis
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 256;
-            int mm, kk;
-            if (g.transA) { kk = e >> 6; mm = e & 63; } else { mm = e >> 4; kk = e & 15; }
-            const int m = m0 + mm, k = k0 + kk;
-            float v = 0.f;
-            if (m < g.M && k < g.K) v = g.transA ? g.A[(size_t)k * g.lda + m] : g.A[(size_t)m * g.lda + k];
-            As[kk][mm] = v;
-            int nn, kb2;
-            if (g.transB) { nn = e >> 4; kb2 = e & 15; } else { kb2 = e >> 6; nn = e & 63; }
-            const int n = n0 + nn, k2 = k0 + kb2;
-            float w = 0.f;
-            if (n < g.N && k2 < g.K) w = g.transB ? g.B[(size_t)n * g.ldb + k2] : g.B[(size_t)k2 * g.ldb + n];
-            Bs[kb2][nn] = w;
+            const int m = m0 + a_mm[i], k = k0 + a_kk[i];
+            ra[i] = (m < g.M && k < g.K) ? (g.transA ? g.A[(size_t)k * g.lda + m] : g.A[(size_t)m * g.lda + k]) : 0.f;
+            const int n = n0 + b_nn[i], k2 = k0 + b_kk[i];
+            rb[i] = (n < g.N && k2 < g.K) ? (g.transB ? g.B[(size_t)n * g.ldb + k2] : g.B[(size_t)k2 * g.ldb + n]) : 0.f;
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int kt = kb; kt < ke; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            As[a_kk[i]][a_mm[i]] = ra[i];
+            Bs[b_kk[i]][b_nn[i]] = rb[i];
         }
         __syncthreads();
+        if (kt + 1 < ke) fetch(kt + 1);                      // next tile's global loads fly under this tile's MFMAs
 #pragma unroll
         for (int k4 = 0; k4 < BK; k4 += 4) {
             float a[2], b[2];
@@ -70,30 +79,39 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
             for (int i = 0; i < 2; ++i) a[i] = As[k4 + fq][wm * 32 + i * 16 + fr];
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = Bs[k4 + fq][wn * 32 + j * 16 + fr];
+            // operand roles swapped (matrix B feeds MFMA operand A): each lane ends up with 4 CONSECUTIVE n of one m
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[j][i], 0, 0, 0);
         }
         __syncthreads();
     }
-    // D layout: row = (lane>>4)*4 + r (A index = m), col = lane&15 (B index = n)
+    // D layout: row = (lane>>4)*4 + r -> n, col = lane&15 -> m
+    const bool slab = g.splitk > 1;
+    float *base = slab ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const int ld = slab ? g.N : g.ldc;
+    const bool vec = ((ld & 3) == 0) && ((g.N & 3) == 0) && ((((uintptr_t)base) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + fq * 4 + r, n = n0 + wn * 32 + j * 16 + fr;
-                if (m < g.M && n < g.N) {
-                    if (g.splitk > 1) {                      // deterministic split-K: one slab per split, summed in order
-                        g.ws[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
-                    } else {
-                        float *c = g.C + (size_t)m * g.ldc + n;
-                        *c = g.alpha * acc[i][j][r] + (g.beta != 0.f ? g.beta * *c : 0.f);
-                    }
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + fr, n = n0 + wn * 32 + j * 16 + fq * 4;
+            if (m >= g.M || n >= g.N) continue;
+            float *c = base + (size_t)m * ld + n;
+            floatx4t v = acc[j][i];
+            if (vec) {
+                if (!slab) {
+                    v *= g.alpha;
+                    if (g.beta != 0.f) v += g.beta * *(const floatx4t *)c;
                 }
+                *(floatx4t *)c = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) c[r] = slab ? v[r] : g.alpha * v[r] + (g.beta != 0.f ? g.beta * c[r] : 0.f);
             }
+        }
 }
 
 __global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict__ ws, int splits, int M, int N, float alpha, float beta,
@@ -119,8 +137,8 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int nk = (K + 15) / 16;
     int s = 1;
-    if (tiles < 256 && nk >= 64) {            // weight gradients: tiny output, reduction over all pixels
-        s = (int)std::min<long>((512 + tiles - 1) / tiles, nk / 16);
+    if (tiles < 512 && nk >= 8) {             // small grids (weight gradients, late 7x10 / 14x20 layers): fill the 256 CUs with K slices
+        s = (int)std::min<long>((1024 + tiles - 1) / tiles, nk / 4);
         if (s < 1) s = 1;
         if (s > 256) s = 256;
     }
@@ -139,6 +157,38 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
         hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta, C,
                            ldc);
     }
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+
+// <x, y> in two fixed-order stages (the l2 regulariser's value): out = alpha * dot + beta * out
+__global__ void __launch_bounds__(256) dot_partial_kernel(size_t n, const float *__restrict__ x, const float *__restrict__ y, double *__restrict__ part) {
+    __shared__ double red[256];
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)x[i] * (double)y[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(64) dot_finish_kernel(const double *__restrict__ part, int blocks, float alpha, float beta, float *__restrict__ out) {
+    double s = 0;
+    for (int k = threadIdx.x; k < blocks; k += 64) s += part[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) *out = alpha * (float)s + (beta != 0.f ? beta * *out : 0.f);
+}
+extern "C" int yk_dot_f32(long long n, const float *x, const float *y, float alpha, float beta, float *out, void *stream) {
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    const int blocks = (int)std::min<long long>(512, (n + 255) / 256);
+    double *part = (double *)yk_scratch(dev, stream, 15, sizeof(double) * 512);
+    if (!part) return YK_ERR_NOMEM;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, x, y, part);
+    hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)part, blocks, alpha, beta, out);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
@@ -256,43 +306,97 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(conv_geom q, const flo
     dx[i] = s;
 }
 
-// dw[t][c] = sum_{b,oy,ox} dy * x(tap t).  grid (chunks, ceil(C/64)), block (64 channels x 4 row-lanes);
-// partial[chunk][9][C] then summed in chunk order by dw_bwd_weight_finish (deterministic).
-__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
-                                                            float *__restrict__ partial, int rows_per_chunk) {
-    __shared__ float red[9][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    const size_t M = (size_t)q.B * q.Ho * q.Wo;
-    const size_t r0 = (size_t)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (c < q.C)
-        for (size_t m = r0 + rl; m < r1; m += 4) {
-            const int ox = (int)(m % q.Wo), oy = (int)((m / q.Wo) % q.Ho), b = (int)(m / ((size_t)q.Wo * q.Ho));
-            const float g = dy[m * q.C + c];
+// Column-sum finish shared by every two-stage reduction here: one wavefront per output element, lanes stride over the
+// chunks and fold with a fixed xor tree — deterministic, and 64x shorter than a serial walk over 512 chunks.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = oy * q.stride - q.pad_t + t / 3, ix = ox * q.stride - q.pad_l + t % 3;
-                if ((unsigned)iy < (unsigned)q.Hi && (unsigned)ix < (unsigned)q.Wi)
-                    s[t] += g * x[(((size_t)b * q.Hi + iy) * q.Wi + ix) * q.C + c];
-            }
-        }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) red[t][rl][cl] = s[t];
-    __syncthreads();
-    if (rl == 0 && c < q.C)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-            partial[((size_t)blockIdx.x * 9 + t) * q.C + c] = red[t][0][cl] + red[t][1][cl] + red[t][2][cl] + red[t][3][cl];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restrict__ partial, int chunks, int n, float *__restrict__ out,
                                                             float scale) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * n + i];
-    out[i] = s * scale;
+    for (int k = lane; k < chunks; k += 64) s += partial[(size_t)k * n + i];
+    s = wave_sum(s);
+    if (lane == 0) out[i] = s * scale;
 }
+
+// dw[t][c] = sum_{b,oy,ox} dy * x(tap t).  One thread = one channel x one output row: it slides a 3x3 register window along
+// ox, so each step loads 3*stride new inputs instead of 9.  block = CW channel lanes x (256/CW) row lanes; grid (row chunks,
+// channel groups); partial[chunk][9][C] is folded by colsum_finish_kernel.
+__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
+                                                            float *__restrict__ partial, int rows_per_chunk, int cw_log2) {
+    __shared__ float red[9][256];
+    const int CW = 1 << cw_log2, RL = 256 >> cw_log2;
+    const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_log2;
+    const int c = blockIdx.y * CW + cl;
+    const int rows = q.B * q.Ho;
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < q.C)
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const int b = r / q.Ho, oy = r - b * q.Ho;
+            const float *xr[3];
+            bool rv[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * q.stride - q.pad_t + ky;
+                rv[ky] = (unsigned)iy < (unsigned)q.Hi;
+                xr[ky] = x + (((size_t)b * q.Hi + (rv[ky] ? iy : 0)) * q.Wi) * q.C + c;
+            }
+            const float *gr = dy + ((size_t)r * q.Wo) * q.C + c;
+            float w[3][3];
+            auto ld = [&](int ky, int ix) -> float { return (rv[ky] && (unsigned)ix < (unsigned)q.Wi) ? xr[ky][(size_t)ix * q.C] : 0.f; };
+            int ix0 = -q.pad_l;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                w[ky][0] = 0.f;                       // filled by the first shift below
+                w[ky][1] = ld(ky, ix0);
+                w[ky][2] = ld(ky, ix0 + 1);
+            }
+            if (q.stride == 1) {
+                for (int ox = 0; ox < q.Wo; ++ox) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        w[ky][0] = w[ky][1];
+                        w[ky][1] = w[ky][2];
+                        w[ky][2] = ld(ky, ox - q.pad_l + 2);
+                    }
+                    const float g = gr[(size_t)ox * q.C];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) s[t] += g * w[t / 3][t % 3];
+                }
+            } else {
+                for (int ox = 0; ox < q.Wo; ++ox) {
+                    const int ix = ox * q.stride - q.pad_l;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        w[ky][0] = (ox && q.stride == 2) ? w[ky][2] : ld(ky, ix);
+                        w[ky][1] = ld(ky, ix + 1);
+                        w[ky][2] = ld(ky, ix + 2);
+                    }
+                    const float g = gr[(size_t)ox * q.C];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) s[t] += g * w[t / 3][t % 3];
+                }
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = s[t];
+    __syncthreads();
+    if (rl == 0 && c < q.C)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float a = 0.f;
+            for (int k = 0; k < RL; ++k) a += red[t][k * CW + cl];
+            partial[((size_t)blockIdx.x * 9 + t) * q.C + c] = a;
+        }
+}
+
+static int lane_split(int C) { return C <= 16 ? 4 : (C <= 32 ? 5 : 6); }      // log2 of the channel lanes per block
 
 static int chunking(size_t M, int *rows_per_chunk) {
     int chunks = (int)std::min<size_t>(512, (M + 255) / 256);
@@ -322,13 +426,14 @@ extern "C" int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, i
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    int rpc;
-    const int chunks = chunking((size_t)B * Ho * Wo, &rpc);
+    const int cwl = lane_split(C), RL = 256 >> cwl, rows = B * Ho;
+    int rpc = ((rows + 511) / 512 + RL - 1) / RL * RL;          // whole row-lane rounds per chunk, at most ~512 chunks
+    const int chunks = (rows + rpc - 1) / rpc;
     float *partial = (float *)yk_scratch(dev, stream, 12, sizeof(float) * (size_t)chunks * 9 * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, q, x, dy, partial, rpc);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, partial, chunks, 9 * C, dw, 1.f);
+    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, q, x, dy, partial, rpc, cwl);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((9 * C + 3) / 4), dim3(256), 0, st, partial, chunks, 9 * C, dw, 1.f);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
@@ -352,54 +457,89 @@ __device__ __forceinline__ float t_act_grad(float pre, int act, float alpha) {  
     return 1.f;
 }
 
-// mode 0: sum z ; mode 1: sum (z-mean)^2 ; mode 2: sums of g and g*xhat (two outputs)
-__global__ void __launch_bounds__(256) bn_colreduce_kernel(int mode, const float *__restrict__ z, const float *__restrict__ dy, size_t M,
-                                                           int C, int rows_per_chunk, const float *__restrict__ mean,
+// Column reductions over the M rows of z [M][C].  block = CW channel lanes x (256/CW) row lanes, grid (row chunks, channel
+// groups).  STATS: sum z and sum z^2 in one pass, accumulated in double (mean and E[z^2]-mean^2 from fp32 data lose nothing at
+// double precision).  BWD: sums of g and g*xhat with g = dy * act'(.) in float.
+template <bool STATS>
+__global__ void __launch_bounds__(256) bn_colreduce_kernel(const float *__restrict__ z, const float *__restrict__ dy, size_t M, int C,
+                                                           int rows_per_chunk, int cw_log2, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, int act, float alpha,
-                                                           float *__restrict__ partial) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+                                                           const float *__restrict__ beta, int act, float alpha, void *__restrict__ partial_v) {
+    using acc_t = typename std::conditional<STATS, double, float>::type;
+    __shared__ acc_t red[2][256];
+    const int CW = 1 << cw_log2, RL = 256 >> cw_log2;
+    const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_log2;
+    const int c = blockIdx.y * CW + cl;
     const size_t r0 = (size_t)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-    float s0 = 0.f, s1 = 0.f;
+    acc_t s0 = 0, s1 = 0;
     if (c < C) {
-        const float mu = mode ? mean[c] : 0.f;
-        const float is = mode == 2 ? invstd[c] : 0.f, ga = mode == 2 ? gamma[c] : 0.f, be = mode == 2 ? beta[c] : 0.f;
-        for (size_t m = r0 + rl; m < r1; m += 4) {
-            const float v = z[m * C + c];
-            if (mode == 0) s0 += v;
-            else if (mode == 1) s0 += (v - mu) * (v - mu);
-            else {
-                const float xh = (v - mu) * is;
+        if (STATS) {
+            for (size_t m = r0 + rl; m < r1; m += RL) {
+                const double v = (double)z[m * C + c];
+                s0 += v;
+                s1 += v * v;
+            }
+        } else {
+            const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+            for (size_t m = r0 + rl; m < r1; m += RL) {
+                const float xh = (z[m * C + c] - mu) * is;
                 const float g = dy[m * C + c] * t_act_grad(ga * xh + be, act, alpha);
                 s0 += g;
                 s1 += g * xh;
             }
         }
     }
-    red[0][rl][cl] = s0;
-    red[1][rl][cl] = s1;
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
     __syncthreads();
     if (rl == 0 && c < C) {
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        acc_t a = 0, b = 0;
+        for (int k = 0; k < RL; ++k) {
+            a += red[0][k * CW + cl];
+            b += red[1][k * CW + cl];
+        }
+        acc_t *partial = (acc_t *)partial_v;
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
     }
 }
-// out0[c] = scale * sum_k partial[k][0][c] ; out1[c] likewise (when out1 != null); optional var -> invstd
-__global__ void __launch_bounds__(256) bn_finish_kernel(const float *__restrict__ partial, int chunks, int C, float scale, float eps,
-                                                        int to_invstd, float *__restrict__ out0, float *__restrict__ out1,
-                                                        float *__restrict__ raw0) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+// one wavefront per channel folds the chunk partials
+__global__ void __launch_bounds__(256) bn_stats_finish_kernel(const double *__restrict__ partial, int chunks, int C, double invM, float eps,
+                                                              float *__restrict__ mean, float *__restrict__ invstd,
+                                                              float *__restrict__ var_out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < chunks; ++k) {
+    double a = 0, b = 0;
+    for (int k = lane; k < chunks; k += 64) {
         a += partial[((size_t)k * 2 + 0) * C + c];
         b += partial[((size_t)k * 2 + 1) * C + c];
     }
-    if (raw0) raw0[c] = a * scale;                         // biased variance, for the moving statistics
-    out0[c] = to_invstd ? 1.f / sqrtf(a * scale + eps) : a * scale;
-    if (out1) out1[c] = b * scale;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        const double mu = a * invM;
+        double var = b * invM - mu * mu;                 // biased (population) variance, as tf.nn.moments
+        if (var < 0) var = 0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (var_out) var_out[c] = (float)var;
+    }
+}
+__global__ void __launch_bounds__(256) bn_bwd_finish_kernel(const float *__restrict__ partial, int chunks, int C, float *__restrict__ dbeta,
+                                                            float *__restrict__ dgamma) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int k = lane; k < chunks; k += 64) {
+        a += partial[((size_t)k * 2 + 0) * C + c];
+        b += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        dbeta[c] = a;
+        if (dgamma) dgamma[c] = b;
+    }
 }
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float *__restrict__ z, size_t total, int C, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
@@ -428,26 +568,32 @@ __global__ void __launch_bounds__(256) moving_update_kernel(float *mm, float *mv
     mv[c] = mv[c] * mom + var[c] * (1.f - mom);
 }
 
+static int bn_chunking(size_t M, int C, int *rows_per_chunk, int *cwl) {
+    *cwl = lane_split(C);
+    const int RL = 256 >> *cwl;
+    size_t rpc = ((M + 511) / 512 + RL - 1) / RL * RL;
+    if (rpc < (size_t)RL) rpc = RL;
+    *rows_per_chunk = (int)rpc;
+    return (int)((M + rpc - 1) / rpc);
+}
+
 extern "C" int yk_bn_train_fwd_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
                                    float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
                                    float *moving_var, float momentum, void *stream) {
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    int rpc;
-    const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
-    if (!partial) return YK_ERR_NOMEM;
-    float *var = partial + (size_t)chunks * 2 * C;
+    int rpc, cwl;
+    const int chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
+    char *ws = (char *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
+    if (!ws) return YK_ERR_NOMEM;
+    double *partial = (double *)ws;
+    float *var = (float *)(ws + sizeof(double) * (size_t)chunks * 2 * C);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(chunks, (C + 63) / 64);
-    hipLaunchKernelGGL(bn_colreduce_kernel, grid, dim3(256), 0, st, 0, z, (const float *)nullptr, (size_t)M, C, rpc, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, 0.f, partial);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, chunks, C, 1.f / (float)M, 0.f, 0, save_mean,
-                       (float *)nullptr, (float *)nullptr);
-    hipLaunchKernelGGL(bn_colreduce_kernel, grid, dim3(256), 0, st, 1, z, (const float *)nullptr, (size_t)M, C, rpc, (const float *)save_mean,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, 0.f, partial);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, chunks, C, 1.f / (float)M, eps, 1, save_invstd,
-                       (float *)nullptr, var);
+    hipLaunchKernelGGL(bn_colreduce_kernel<true>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, (const float *)nullptr,
+                       (size_t)M, C, rpc, cwl, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
+                       0.f, (void *)partial);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const double *)partial, chunks, C, 1.0 / (double)M, eps,
+                       save_mean, save_invstd, var);
     const size_t total = (size_t)M * C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
                        (const float *)save_invstd, gamma, beta, act, alpha, y);
@@ -463,15 +609,14 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
                                    float *dbeta, void *stream) {
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    int rpc;
-    const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
+    int rpc, cwl;
+    const int chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
+    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_colreduce_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, 2, z, dy, (size_t)M, C, rpc, save_mean, save_invstd,
-                       gamma, beta, act, alpha, partial);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, chunks, C, 1.f, 0.f, 0, dbeta, dgamma,
-                       (float *)nullptr);
+    hipLaunchKernelGGL(bn_colreduce_kernel<false>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, dy, (size_t)M, C, rpc, cwl,
+                       save_mean, save_invstd, gamma, beta, act, alpha, (void *)partial);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const float *)partial, chunks, C, dbeta, dgamma);
     const size_t total = (size_t)M * C;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, dy, total, C, 1.f / (float)M, save_mean,
                        save_invstd, gamma, beta, (const float *)dbeta, (const float *)dgamma, act, alpha, dz);
@@ -490,18 +635,26 @@ extern "C" int yk_bias_add_f32(float *y, long long M, int C, const float *bias, 
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
+__global__ void __launch_bounds__(256) colsum_from_stats_kernel(const double *__restrict__ partial, int chunks, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double a = 0;
+    for (int k = lane; k < chunks; k += 64) a += partial[((size_t)k * 2 + 0) * C + c];
+    a = wave_sum(a);
+    if (lane == 0) out[c] = (float)a;
+}
 extern "C" int yk_colsum_f32(const float *x, long long M, int C, float *out, void *stream) {
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    int rpc;
-    const int chunks = chunking((size_t)M, &rpc);
-    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(float) * ((size_t)chunks * 2 * C + C));
+    int rpc, cwl;
+    const int chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
+    double *partial = (double *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_colreduce_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, st, 0, x, (const float *)nullptr, (size_t)M, C, rpc,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, 0.f, partial);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, chunks, C, 1.f, 0.f, 0, out, (float *)nullptr,
-                       (float *)nullptr);
+    hipLaunchKernelGGL(bn_colreduce_kernel<true>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, x, (const float *)nullptr, (size_t)M,
+                       C, rpc, cwl, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, 0.f,
+                       (void *)partial);
+    hipLaunchKernelGGL(colsum_from_stats_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const double *)partial, chunks, C, out);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

@@ -71,7 +71,7 @@ def lib() -> C.CDLL:
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
                    'yk_bias_add_f32', 'yk_colsum_f32', 'yk_upsample2x_bwd_f32', 'yk_maxpool2_fwd_f32',
-                   'yk_maxpool2_bwd_f32', 'yk_axpy_f32', 'yk_adam_f32'):
+                   'yk_maxpool2_bwd_f32', 'yk_axpy_f32', 'yk_adam_f32', 'yk_dot_f32'):
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
         _lib = L

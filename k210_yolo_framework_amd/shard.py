@@ -55,3 +55,13 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allreduce_gradients(flat_grad, dist=None, group=None):
+    """Training-step exchange: ONE sum all-reduce over the whole flat gradient bucket (a few MB for the
+    MobileNet detectors — a single large ring pass is what per-link-bound xGMI wants).  Each rank's gradient already
+    carries the 1/global_batch factor, so the sum is the global-batch gradient.  In place; returns the tensor."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat_grad
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad

@@ -23,7 +23,8 @@ from . import engine
 from . import netspec as ns
 
 L2_WEIGHT = 5e-4                 # keras.regularizers.l2(5e-4), yolonet.py:247
-BN_MOMENTUM = 0.99               # keras BatchNormalization default
+BN_MOMENTUM = 0.99               # keras BatchNormalization default (v1 backbone, every DarknetConv2D_BN_Leaky)
+BN_MOMENTUM_V2 = 0.999           # MobileNetV2 backbone, keras_mobilenet_v2.py:320
 
 
 def _is_darknet_conv(name: str) -> bool:
@@ -184,7 +185,8 @@ class Trainer:
                         engine._ptr(self.view(self.P, l.bn_name + '/beta')), C.c_float(ns.BN_EPS), C.c_int(op['act']),
                         C.c_float(op['alpha']), engine._ptr(y), engine._ptr(mean), engine._ptr(invstd),
                         engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
-                        C.c_float(BN_MOMENTUM), self._s()), 'yk_bn_train_fwd_f32')
+                        C.c_float(BN_MOMENTUM_V2 if self.spec.name == 'yolo_mobilev2' and not _is_darknet_conv(l.name) else BN_MOMENTUM),
+                        self._s()), 'yk_bn_train_fwd_f32')
                     S[i] = dict(z=z, mean=mean, invstd=invstd)
                 else:
                     assert op['act'] == ns.ACT_NONE
@@ -315,7 +317,8 @@ class Trainer:
             if l.kind == 'conv' and _is_darknet_conv(l.name):
                 w = self.view(self.P, l.name + '/kernel')
                 n = w.numel()
-                self.gemm(0, 1, 1, 1, n, w, n, w, n, tot, 1, alpha=L2_WEIGHT, beta=1.0)   # tot += 5e-4 * <w, w>
+                self._ck(self.L.yk_dot_f32(C.c_longlong(n), engine._ptr(w), engine._ptr(w), C.c_float(L2_WEIGHT), C.c_float(1.0),
+                                           engine._ptr(tot), self._s()), 'yk_dot_f32')                    # tot += 5e-4 * <w, w>
                 if add_grad:
                     self._axpy(2.0 * L2_WEIGHT, w, self.view(self.G, l.name + '/kernel'))
         return tot
@@ -340,9 +343,10 @@ class Trainer:
         r = self.loss_and_grads(x_nhwc, y_true)
         if self.world > 1:
             import torch.distributed as dist
+            from .shard import allreduce_gradients
             # data-term gradients already carry 1/global_batch, so SUM over ranks is the global-batch gradient;
             # the regulariser's gradient is identical on every rank and is added once, after the reduction
-            dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.pg)
+            allreduce_gradients(self.G, dist, self.pg)
             self.regulariser(add_grad=True)
         self._ck(self.L.yk_adam_f32(C.c_longlong(self.n_params), engine._ptr(self.P), engine._ptr(self.G), engine._ptr(self.m),
                                     engine._ptr(self.v), C.c_float(self.lr), C.c_float(self.decay), C.c_longlong(self.iterations),

@@ -123,7 +123,7 @@ def yolo_loss_torch(yt, yp, anchors, obj_thresh, iou_thresh, ow, nw, ww, batch_s
 
 
 def loss_and_grads(spec: ns.NetSpec, weights: Dict[str, np.ndarray], x_nhwc: np.ndarray, y_true: Sequence[np.ndarray], anchors,
-                   obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0, batch_size=None, want_pre=False):
+                   obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0, batch_size=None, want_pre=False, with_reg=True):
     """-> (data_loss, reg_loss, grads dict in Keras layout, bn batch stats)."""
     trainable = [k for k in weights if not k.endswith(('/moving_mean', '/moving_variance'))]
     params = {k: torch.from_numpy(np.asarray(weights[k], np.float64)).requires_grad_(True) for k in trainable}
@@ -134,7 +134,7 @@ def loss_and_grads(spec: ns.NetSpec, weights: Dict[str, np.ndarray], x_nhwc: np.
     data = sum(yolo_loss_torch(torch.from_numpy(np.asarray(yt, np.float64)), yp, anchors[i], obj_thresh, iou_thresh, obj_weight,
                                noobj_weight, wh_weight, bs) for i, (yt, yp) in enumerate(zip(y_true, preds)))
     reg = sum(L2_WEIGHT * (params[l.name + '/kernel'] ** 2).sum() for l in spec.layers if l.kind == 'conv' and _is_darknet_conv(l.name))
-    (data + reg).backward()
+    (data + reg if with_reg else data).backward()
     stats.pop('__want_pre__', None)
     grads = {k: (p.grad.numpy() if p.grad is not None else np.zeros(p.shape)) for k, p in params.items()}
     return float(data.detach()), float(reg.detach()), grads, stats, [p.detach().numpy() for p in preds]
