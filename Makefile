@@ -19,6 +19,8 @@ IOUTHRESH=0.5
 IMGSIZE=224 320
 OUTSIZE=7 10 14 20
 GPUS=1
+PRUNE=False
+SYNTHETIC=0
 
 all:
 	@echo please use \"make build\", \"make inference\", \"make bench\", \"make test\" ...
@@ -40,9 +42,29 @@ inference:
 			--output_size ${OUTSIZE}
 
 train:
-	@echo "make train (keras_train.py: YOLO loss + Adam + RCCL gradient all-reduce) is SURVEY.md 8(a) rows T1-T5 /"
-	@echo "BASELINE config 4; the backward kernels are not built yet in this round - see DESIGN.md 'what comes next'."
-	@false
+	python3 ./keras_train.py \
+			--train_set ${DATASET} \
+			--class_num ${CLSNUM} \
+			--pre_ckpt ${CKPT} \
+			--model_def ${MODEL} \
+			--depth_multiplier ${DEPTHMUL} \
+			--augmenter ${IAA} \
+			--image_size ${IMGSIZE} \
+			--output_size ${OUTSIZE} \
+			--batch_size ${BATCH} \
+			--rand_seed 3 \
+			--max_nrof_epochs ${MAXEP} \
+			--init_learning_rate ${ILR} \
+			--learning_rate_decay_factor ${LRDECAYFACTOR} \
+			--obj_weight ${OBJWEIGHT} \
+			--noobj_weight ${NOOBJWEIGHT} \
+			--wh_weight ${WHWEIGHT} \
+			--obj_thresh ${OBJTHRESH} \
+			--iou_thresh ${IOUTHRESH} \
+			--vaildation_split ${SPLITFACTOR} \
+			--log_dir log \
+			--is_prune ${PRUNE} \
+			--synthetic ${SYNTHETIC}
 
 bench:
 	python3 bench.py --gpus ${GPUS}

@@ -384,3 +384,17 @@ def test_rccl_allreduce_of_the_flat_gradient_bucket_single_rank_group():
         assert shard.allreduce_gradients(tr.G, dist) is tr.G
     finally:
         dist.destroy_process_group()
+
+
+def test_make_train_cli_synthetic_run_saves_a_checkpoint_the_inference_model_loads(tmp_path, monkeypatch):
+    from k210_yolo_framework_amd import training, yolonet
+    tr = training.cli(['--synthetic', '40', '--model_def', 'yolo_mobilev1', '--depth_multiplier', '0.5', '--batch_size', '8',
+                       '--max_nrof_epochs', '3', '--init_learning_rate', '0.001', '--vaildation_split', '0.2', '--log_dir', str(tmp_path),
+                       '--obj_weight', '1', '--noobj_weight', '1', '--wh_weight', '1', '--iou_thresh', '0.5'])
+    ck = list(tmp_path.glob('*/yolo_model.npz'))
+    assert len(ck) == 1 and (ck[0].parent / 'args.txt').exists()
+    assert tr.iterations == 12                                            # 32 training images / 8 per step * 3 epochs
+    model, wrapper = yolonet.yolo_mobilev1([224, 320, 3], 3, 20, alpha=0.5)
+    wrapper.load_weights(str(ck[0]))
+    y = wrapper.predict(np.random.default_rng(0).uniform(0, 1, (2, 224, 320, 3)).astype(np.float32))
+    assert [t.shape for t in y] == [(2, 7, 10, 3, 25), (2, 14, 20, 3, 25)] and all(np.isfinite(t).all() for t in y)
