@@ -536,7 +536,8 @@ struct igemm_cfg_info {
 static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
     {128, 64, 32, "igemm_128x64"}, {128, 48, 32, "igemm_128x48"}, {128, 96, 32, "igemm_128x96"},
     {128, 192, 64, "igemm_128x192k64"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 64, "igemm_128x128k64"},
-    {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}};
+    {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}, {128, 64, 64, "igemm_128x64k64"},
+    {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}};
 
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
@@ -548,6 +549,9 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     case IGEMM_128x128: return launch_cfg<128, 128, 2, 2, 64, false, true>(a, st);
     case IGEMM_F32_64x80: return launch_cfg<64, 80, 4, 1, 64, true, true>(a, st);
     case IGEMM_F32_128x64: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
+    case IGEMM_128x64K64: return launch_cfg<128, 64, 2, 2, 64, false, true>(a, st);
+    case IGEMM_64x128: return launch_cfg<64, 128, 2, 2, 64, false, true>(a, st);
+    case IGEMM_64x192: return launch_cfg<64, 192, 2, 2, 64, false, true>(a, st);
     }
     yk_set_error("yk_launch_igemm: bad config %d", cfg);
     return YK_ERR_ARG;
@@ -557,6 +561,13 @@ const char *yk_igemm_name(int cfg) { return (cfg >= 0 && cfg < IGEMM_NUM) ? g_cf
 
 int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     if (out_f32) return a.N <= 80 ? IGEMM_F32_64x80 : IGEMM_F32_128x64;
+    if (a.K >= 1024) {                                               // tuning sweep hook (tools/igemm_sweep.py), long-K convs only
+        const char *f = getenv("YK_IGEMM_FORCE");
+        if (f && f[0]) {
+            const int c = atoi(f);
+            if (c >= 0 && c < IGEMM_NUM && c != IGEMM_F32_64x80 && c != IGEMM_F32_128x64 && a.N % g_cfg[c].bn == 0) return c;
+        }
+    }
     const long mt128 = (a.M + 127) / 128;
     if (a.N == 48) return IGEMM_128x48;
     if (a.N == 96) return IGEMM_128x96;
@@ -576,6 +587,10 @@ int yk_igemm_split(int cfg, const igemm_args &a) {
     const igemm_cfg_info &c = g_cfg[cfg];
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const int nk = (a.K + c.bk - 1) / c.bk;
+    if (a.K >= 1024) {
+        const char *f = getenv("YK_SPLIT_FORCE");
+        if (f && f[0]) return std::max(1, std::min(atoi(f), nk));
+    }
     if (tiles >= 384 || nk < 6) return 1;
     const long target = ((long)c.bm * c.bn >= 128 * 128) ? 512 : 1024;
     long s = (target + tiles - 1) / tiles;

@@ -102,9 +102,27 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             if (f && pos < YK_NMS_MAXC) {
                 L.s[pos] = sv[u];
                 L.idx[pos] = i;
-                L.box[pos] = bx[i];
             }
             n += __popcll(m);
+        }
+    }
+    __syncthreads();
+    // boxes of the candidates, fetched in bulk AFTER the scan: a load inside the ballot loop above would put one global
+    // round trip on the critical path per unrolled step (measured: 24 serialised latencies, ~40 us of a 53 us kernel)
+    {
+        const int nc = min(n, YK_NMS_MAXC);
+        for (int c0 = 0; c0 < nc; c0 += 256) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                t[u] = bx[c < nc ? L.idx[c] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c < nc) L.box[c] = t[u];
+            }
         }
     }
     __syncthreads();
@@ -114,35 +132,59 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
         // candidates in descending score order and test each against the boxes selected so far.  The selected
         // boxes live one per lane in registers, so a candidate costs one IoU + one ballot: no LDS writes, no barriers.
         int *ord = reinterpret_cast<int *>(L.box + YK_NMS_MAXC) - 512;   // tail of the box array is free (n <= 512)
-        for (int c = lane; c < n; c += 64) {                              // rank sort: (score desc, box index asc)
-            const float sc_c = L.s[c];
-            const int ic = L.idx[c];
+        unsigned long long *key = reinterpret_cast<unsigned long long *>(ord) - 512;
+        // rank sort on one 64-bit key per candidate: (score bits, ~box index) — scores are >= 0, so the bit pattern orders
+        // like the float; ties fall to the lower box index
+        for (int c = lane; c < n; c += 64)
+            key[c] = ((unsigned long long)__float_as_uint(L.s[c]) << 32) | (unsigned)(~L.idx[c]);
+        __syncthreads();
+        for (int c = lane; c < n; c += 64) {
+            const unsigned long long kc = key[c];
             int r = 0;
-            for (int j = 0; j < n; ++j) {
-                const float sj = L.s[j];
-                r += (sj > sc_c || (sj == sc_c && L.idx[j] < ic)) ? 1 : 0;
-            }
+            for (int j = 0; j < n; ++j) r += key[j] > kc ? 1 : 0;
             ord[r] = c;
+            // corners normalised once (tf_iou does it per call; min/max are idempotent, so the other paths are unaffected)
+            const float4 q = L.box[c];
+            L.box[c] = make_float4(fminf(q.x, q.z), fminf(q.y, q.w), fmaxf(q.x, q.z), fmaxf(q.y, q.w));
         }
         __syncthreads();
-        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+        // iou > thr is decided without the division whenever inter is clearly above / below thr*union (2e-6 guard band, 30x the
+        // rounding of the quotient); only the band itself takes the exact fp32 division the reference performs
+        const bool guard = iou_thresh > 0.f;
+        const float thr_hi = guard ? iou_thresh * (1.f + 2e-6f) : INFINITY, thr_lo = guard ? iou_thresh * (1.f - 2e-6f) : -INFINITY;
+        float my0 = 0.f, mx0 = 0.f, my1 = 0.f, mx1 = 0.f, ma = 0.f;
         // candidates are pulled into registers 64 at a time (lane t holds the t-th best of the block) and handed
         // out with v_readlane: the serial loop has no dependent LDS read in it
         for (int base = 0; base < n && kept < max_out; base += 64) {
             const int me = base + lane;
             const int pos = (me < n) ? ord[me] : 0;
             const float4 bb = L.box[pos];
+            const float ar = (bb.z - bb.x) * (bb.w - bb.y);
             const float sv = L.s[pos];
             const int iv = L.idx[pos];
             const int cnt = min(64, n - base);
             for (int t = 0; t < cnt && kept < max_out; ++t) {
-                const float4 cb = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.x), t)),
-                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.y), t)),
-                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.z), t)),
-                                              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.w), t)));
-                const bool hit = (lane < kept) && (tf_iou(cb, mine) > iou_thresh);
-                if (__ballot(hit) == 0ull) {
-                    if (lane == kept) mine = cb;
+                const float cy0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.x), t));
+                const float cx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.y), t));
+                const float cy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.z), t));
+                const float cx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bb.w), t));
+                const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ar), t));
+                const float inter = fmaxf(fminf(cy1, my1) - fmaxf(cy0, my0), 0.f) * fmaxf(fminf(cx1, mx1) - fmaxf(cx0, mx0), 0.f);
+                const float uni = ca + ma - inter;
+                const bool valid = (lane < kept) && (ca > 0.f) && (ma > 0.f);          // zero-area boxes never overlap (TF)
+                unsigned long long hits = __ballot(valid && inter > thr_hi * uni);
+                if (hits == 0ull) {
+                    const bool band = valid && inter >= thr_lo * uni;
+                    if (__ballot(band) != 0ull) hits = __ballot(band && (inter / uni > iou_thresh));
+                }
+                if (hits == 0ull) {
+                    if (lane == kept) {
+                        my0 = cy0;
+                        mx0 = cx0;
+                        my1 = cy1;
+                        mx1 = cx1;
+                        ma = ca;
+                    }
                     const int gi = __builtin_amdgcn_readlane(iv, t);
                     const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), t));
                     if (lane == 0) {
