@@ -65,11 +65,13 @@ struct igemm_args {
     const float *dw_scale, *dw_bias;
     int dw_act, dw_stride, dw_pad_t, dw_pad_l, dw_Hi, dw_Wi;
     float dw_slope, dw_cap;
+    int lda_pad;                // LDS pitch padding (halfs) of the fused kernels' depthwise tile (yk_fused_pad())
     long long *dbg;             // dev instrumentation: per-workgroup phase timestamps (null in production)
 };
 enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_64x80,
        IGEMM_F32_128x64, IGEMM_128x64K64, IGEMM_64x128, IGEMM_64x192, IGEMM_NUM };
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st);
+int yk_fused_pad();
 int yk_igemm_pick(const igemm_args &a, bool out_f32);
 // split-K policy for a picked config (1 = no split) and the finishing pass
 int yk_igemm_split(int cfg, const igemm_args &a);

@@ -717,6 +717,11 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     return YK_ERR_ARG;
 }
 
+int yk_fused_pad() {
+    static const int p = getenv("YK_FPAD") ? atoi(getenv("YK_FPAD")) : 16;
+    return (p == 8 || p == 16 || p == 24) ? p : 16;
+}
+
 const char *yk_igemm_name(int cfg) { return (cfg >= 0 && cfg < IGEMM_NUM) ? g_cfg[cfg].name : "?"; }
 
 int yk_igemm_pick(const igemm_args &a, bool out_f32) {
@@ -737,7 +742,7 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     // (loads -> LDS -> barrier -> fragments -> MFMA), so MORE, SMALLER workgroups win: 64x64x64 beats 128x64x32 by 10-15 % and
     // 128x128x64 (1 wave/SIMD) is the slowest everywhere (104x104 64->128: 294 vs 416).  Long reductions therefore take the
     // small tile; short ones keep 128x64, whose per-workgroup fixed cost is amortised over more output.
-    if (a.K >= 512) return (a.N % 128 == 0 && a.K >= 2048 && a.M >= 8192) ? IGEMM_64x128 : IGEMM_64x64;
+    if (a.K >= 512) return (a.N % 128 == 0 && a.N >= 256 && a.K >= 2048 && a.M >= 8192) ? IGEMM_64x128 : IGEMM_64x64;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;
 }
@@ -1003,7 +1008,7 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
     yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + a.lda_pad;
     const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     const int nk = Kp >> 5;
@@ -1190,7 +1195,7 @@ __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
     constexpr int CS_LD = BN + 8;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + a.lda_pad;
     yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
     yk_half *Ws = As + (size_t)BM * LDA;             // depthwise weights [9][Cp]
     const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
@@ -1322,7 +1327,7 @@ template <int TM>
 __global__ void __launch_bounds__(256) fused_lr_kernel(const igemm_args a) {
     constexpr int NT = 256, BM = 64 * TM, TN = 3;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + 8;
+    const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + a.lda_pad;
     const int npass = (a.N + 47) / 48, CS_LD = npass * 48 + 8;
     yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
     yk_half *Ws = As + (size_t)BM * LDA;
@@ -1425,7 +1430,7 @@ template <int TM>
 static int launch_lr(const igemm_args &a, hipStream_t st) {
     constexpr int BM = 64 * TM;
     const int Kp = (a.c0p + 31) & ~31, npass = (a.N + 47) / 48;
-    const size_t lds = ((size_t)BM * (Kp + 8) + (size_t)9 * a.c0p + (size_t)BM * (npass * 48 + 8)) * 2;
+    const size_t lds = ((size_t)BM * (Kp + a.lda_pad) + (size_t)9 * a.c0p + (size_t)BM * (npass * 48 + 8)) * 2;
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_lr_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1578,7 +1583,7 @@ template <int WM, int WN, int TM, int WPF>
 static int launch_wide(const igemm_args &a, hipStream_t st) {
     constexpr int BM = WM * 16 * TM, BN = WN * 16;
     const int Kp = (a.c0p + 31) & ~31;
-    size_t lds = (size_t)BM * (Kp + 8) * 2 + (size_t)9 * a.c0p * 2, cs = (size_t)BM * (BN + 8) * 2;
+    size_t lds = (size_t)BM * (Kp + a.lda_pad) * 2 + (size_t)9 * a.c0p * 2, cs = (size_t)BM * (BN + 8) * 2;
     if (cs > lds) lds = cs;
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
@@ -1594,7 +1599,7 @@ static int launch_wide(const igemm_args &a, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int IT>
 static int launch_fused(const igemm_args &a, hipStream_t st) {
     const int Kp = (a.c0p + 31) & ~31;
-    size_t lds = (size_t)BM * (Kp + 8) * 2, cs = (size_t)BM * (BN + 8) * 2;
+    size_t lds = (size_t)BM * (Kp + a.lda_pad) * 2, cs = (size_t)BM * (BN + 8) * 2;
     if (cs > lds) lds = cs;
     static size_t attr_lds = 64 * 1024;   // opt in to > 64 KiB dynamic LDS only when a layer needs it
     if (lds > attr_lds) {
@@ -1610,7 +1615,7 @@ static int launch_fused(const igemm_args &a, hipStream_t st) {
 bool yk_igemm_fused_ok(int c0p, int cout) {
     // the whole K extent of the depthwise tile must fit LDS at the smallest BM (32 rows)
     const int Kp = (c0p + 31) & ~31;
-    return c0p % 8 == 0 && (size_t)32 * (Kp + 8) * 2 <= 96 * 1024 && (256 / (c0p >> 3)) >= 1 && cout >= 8;
+    return c0p % 8 == 0 && (size_t)32 * (Kp + yk_fused_pad()) * 2 <= 96 * 1024 && (256 / (c0p >> 3)) >= 1 && cout >= 8;
 }
 int yk_igemm_fused_pick(const igemm_args &a) {
     const int G = a.c0p >> 3;

@@ -320,6 +320,7 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             l.kind = K_IGEMM;
             igemm_args &g = l.g;
             memset(&g, 0, sizeof(g));
+            g.lda_pad = yk_fused_pad();
             const tinfo *s0 = &X, *s1 = nullptr;
             int up0 = 0;
             if (X.kind == T_CAT) {
