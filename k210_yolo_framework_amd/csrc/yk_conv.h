@@ -76,6 +76,9 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32);
 // split-K policy for a picked config (1 = no split) and the finishing pass
 int yk_igemm_split(int cfg, const igemm_args &a);
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st);
+// split-K finishing pass + the 1x1 fp32-output conv that consumes it, one launch
+bool yk_reduce_pw_ok(const igemm_args &a, const igemm_args &b, bool b_out_f32);
+int yk_launch_reduce_pw(const igemm_args &a, const igemm_args &b, hipStream_t st);
 const char *yk_igemm_name(int cfg);
 
 // fused DepthwiseConv2D(3x3)+BN+act -> Conv2D(1x1)+BN+act: the depthwise tile is produced straight

@@ -503,6 +503,94 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const igemm_args a) 
     }
 }
 
+// Split-K finishing pass fused with the 1x1 fp32-output conv that follows it (the y1 / y2 heads: Conv3x3+BN+Leaky ->
+// Conv1x1(+bias), yolonet.py:27-29,37-38).  A workgroup owns 16 pixels: it sums their slabs exactly like
+// splitk_reduce_kernel (same order, same epilogue, the fp16 tensor is still written - it is a plan tensor), keeps the 16 x C
+// fp16 tile in LDS and runs the 1x1 conv on it with the MFMA sequence of the igemm kernels (k ascending in steps of 32), so
+// the results are bit-identical to the two separate launches it replaces.  `a` = the split conv, `b` = the 1x1 conv.
+__global__ void __launch_bounds__(256) reduce_pw_kernel(const igemm_args a, const igemm_args b) {
+    yk_half *Xs = reinterpret_cast<yk_half *>(yk_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Kp = (b.c0p + 31) & ~31, LDX = Kp + YK_LDPAD;
+    const int m0 = blockIdx.x * 16;
+    const int n4 = Kp >> 2;
+    const size_t zs = (size_t)a.M * a.ldn;
+    // the 1x1 conv's weight fragments are requested first, so their latency hides behind the slab reduction
+    const int fr = lane & 15, fk = (lane >> 4) * 8, nl4 = (lane >> 4) * 4;
+    const int ntiles = (b.N + 15) >> 4;
+    half8 wf[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int nrow = (wid + 4 * q) * 16 + fr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wf[q][k] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (wid + 4 * q < ntiles && nrow < b.N && k * 32 + fk < b.K) wf[q][k] = *reinterpret_cast<const half8 *>(b.w + (size_t)nrow * b.K + k * 32 + fk);
+        }
+    }
+    for (int item = tid; item < 16 * n4; item += 256) {
+        const int ml = item / n4, n = (item - ml * n4) * 4, m = m0 + ml;
+        half4 h = {0, 0, 0, 0};
+        if (m < a.M && n < a.ldn) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *p = a.slab + (size_t)m * a.ldn + n;
+            for (int z = 0; z < a.split_k; ++z) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + z * zs);
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n), bs = *reinterpret_cast<const float4 *>(a.bias + n);
+            const float v0 = yk_actf(s.x * sc.x + bs.x, a.slope, a.cap), v1 = yk_actf(s.y * sc.y + bs.y, a.slope, a.cap);
+            const float v2 = yk_actf(s.z * sc.z + bs.z, a.slope, a.cap), v3 = yk_actf(s.w * sc.w + bs.w, a.slope, a.cap);
+            if (n < a.outp) {
+                h = half4{(yk_half)v0, (yk_half)v1, (yk_half)v2, (yk_half)v3};
+                *reinterpret_cast<half4 *>(reinterpret_cast<yk_half *>(a.out) + (size_t)m * a.outp + n) = h;
+            }
+        }
+        *reinterpret_cast<half4 *>(Xs + ml * LDX + n) = h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = wid + 4 * q;
+        if (t >= ntiles) break;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k * 32 < Kp) {
+                const half8 xf = *reinterpret_cast<const half8 *>(Xs + fr * LDX + k * 32 + fk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[q][k], xf, acc, 0, 0, 0);
+            }
+        }
+        const int n = t * 16 + nl4, m = m0 + fr;
+        const float4 sc = *reinterpret_cast<const float4 *>(b.scale + n), bs = *reinterpret_cast<const float4 *>(b.bias + n);
+        const float v0 = yk_actf(acc[0] * sc.x + bs.x, b.slope, b.cap), v1 = yk_actf(acc[1] * sc.y + bs.y, b.slope, b.cap);
+        const float v2 = yk_actf(acc[2] * sc.z + bs.z, b.slope, b.cap), v3 = yk_actf(acc[3] * sc.w + bs.w, b.slope, b.cap);
+        if (m < b.M) {
+            float *o = reinterpret_cast<float *>(b.out) + (size_t)m * b.outp + n;
+            if (n + 0 < b.N) o[0] = v0;
+            if (n + 1 < b.N) o[1] = v1;
+            if (n + 2 < b.N) o[2] = v2;
+            if (n + 3 < b.N) o[3] = v3;
+        }
+    }
+}
+
+// can the split conv `a` (fp16 out) and the conv `b` that reads its output be finished by reduce_pw_kernel?
+bool yk_reduce_pw_ok(const igemm_args &a, const igemm_args &b, bool b_out_f32) {
+    return a.split_k > 1 && !a.res && b_out_f32 && b.split_k <= 1 && b.ks == 1 && b.stride == 1 && !b.in1 && !b.up0 && !b.dw_w && !b.res &&
+           b.in0 == reinterpret_cast<const yk_half *>(a.out) && b.c0p == a.outp && b.K == b.c0p && b.c0p % 8 == 0 && b.c0p <= 256 &&
+           b.N <= 128;
+}
+int yk_launch_reduce_pw(const igemm_args &a, const igemm_args &b, hipStream_t st) {
+    const int Kp = (b.c0p + 31) & ~31;
+    const size_t lds = (size_t)16 * (Kp + YK_LDPAD) * 2;
+    hipLaunchKernelGGL(reduce_pw_kernel, dim3((a.M + 15) / 16), dim3(256), lds, st, a, b);
+    return YK_OK;
+}
+
 // =====================================================================================
 // igemm_lin_kernel: the uniform-tap path again, with the K loop as ONE basic block.
 // For an input that is not read through an upsample the tap offset is linear, off = P_row(src) + tapoff(tap, src) + cin*2,

@@ -59,7 +59,7 @@ float h2f_bits(uint16_t h) {
     return f;
 }
 
-enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD, K_U8MAX, K_REDUCE };
+enum { K_FIRST = 1, K_DW, K_IGEMM, K_POOL, K_ADD, K_U8MAX, K_REDUCE, K_REDUCE_PW };
 enum { T_REAL = 0, T_UP = 1, T_CAT = 2 };
 
 struct tinfo {
@@ -74,6 +74,8 @@ struct tinfo {
 struct launch {
     int kind = 0, cfg = 0;
     igemm_args g;
+    igemm_args g2;              // K_REDUCE_PW: the 1x1 conv finished in the same launch
+    int Ho2 = 0, Wo2 = 0;
     first_args f;
     dw_args d;
     pool_args p;
@@ -492,6 +494,24 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             p->L.push_back(r);
         }
     }
+    // split-K finishing pass followed by the 1x1 fp32 head conv that reads it -> one launch (reduce_pw_kernel)
+    if (env_flag("YK_REDUCE_PW", true)) {
+        for (size_t i = 0; i + 1 < p->L.size(); ++i) {
+            launch &r = p->L[i];
+            launch &c = p->L[i + 1];
+            if (r.kind != K_REDUCE || r.out_f32 || c.kind != K_IGEMM) continue;
+            igemm_args cg = c.g;
+            cg.M = r.g.M;
+            if (!yk_reduce_pw_ok(r.g, cg, c.out_f32)) continue;
+            r.kind = K_REDUCE_PW;
+            r.g2 = c.g;
+            r.Ho2 = c.Ho; r.Wo2 = c.Wo;
+            r.name += "+" + c.name.substr(0, c.name.find('['));
+            r.flops += c.flops;
+            r.bytes += c.bytes;
+            p->L.erase(p->L.begin() + i + 1);
+        }
+    }
     if (p->slab_bytes) {
         if ((rc = dev_alloc(p, (void **)&p->d_slab, p->slab_bytes, true))) return fail(rc);
     }
@@ -539,6 +559,13 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
             g.M = batch * l.Ho * l.Wo;
             g.slab = p->d_slab;
             rc = yk_launch_splitk_reduce(g, l.out_f32, st);
+        } break;
+        case K_REDUCE_PW: {
+            igemm_args g = l.g, g2 = l.g2;
+            g.M = batch * l.Ho * l.Wo;
+            g.slab = p->d_slab;
+            g2.M = batch * l.Ho2 * l.Wo2;
+            rc = yk_launch_reduce_pw(g, g2, st);
         } break;
         case K_DW: {
             dw_args d = l.d;
