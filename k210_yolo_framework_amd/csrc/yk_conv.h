@@ -99,6 +99,7 @@ struct first_args {
     int in_f32;
     int B, Hi, Wi, Ho, Wo, stride, pad_t, pad_l, Cout, outp;
     const float *w;             // [27][Cout] fp32 holding fp16-rounded values, tap-major
+    const yk_half *wm;          // [32][32] fp16, MFMA operand order of stem_mfma_kernel (k = ky*8+j | 24+ky), or null
     const float *scale, *bias;
     int act;
     float alpha;

@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const first_args a) {
         unsigned mx = 0;
 #pragma unroll
         for (int j = 0; j < YK_MAXP; ++j) mx = max(mx, a.img_max[b * YK_MAXP + j]);
-        lut[tid] = (float)tid / (float)mx;
+        lut[tid] = (float)(yk_half)((float)tid / (float)mx);   // the normalised image is an fp16 tensor like every other activation
     }
     __syncthreads();
     const int pix = blockIdx.x * 256 + tid;
@@ -892,9 +892,9 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const first_args a) {
             float x[3];
             if (a.in_f32) {
                 const float *p = reinterpret_cast<const float *>(a.in) + off;
-                x[0] = p[0];
-                x[1] = p[1];
-                x[2] = p[2];
+                x[0] = (float)(yk_half)p[0];
+                x[1] = (float)(yk_half)p[1];
+                x[2] = (float)(yk_half)p[2];
             } else {
                 const uint8_t *p = reinterpret_cast<const uint8_t *>(a.in) + off;
                 x[0] = lut[p[0]];
@@ -919,7 +919,97 @@ __global__ void __launch_bounds__(256) first_conv_kernel(const first_args a) {
     }
 }
 
+// Stem as MFMA (u8 frames).  K = 27 is padded to 32 in an order chosen for the loader, not the math: k = ky*8 + j for the first
+// 8 of the 9 contiguous bytes (3 pixels x RGB) a tap row contributes, k = 24 + ky for the ninth, 27..31 zero (`wm` holds the
+// weights in that order).  A lane of the pixel operand (pixel = lane&15, chunk q = lane>>4) therefore needs ONE unaligned 8-byte
+// load (q < 3: row q) or three byte loads (q = 3); left padding falls out of a 64-bit shift, right padding / row overrun out of
+// a shift right, invalid rows out of the buffer bounds check.  Bytes become fp16 through a 256-entry LUT of half(v / max) in LDS.
+// 16 pixels x 32 channels per two MFMAs; the VALU version spends ~985 instructions per wave of 64 pixels on the same work.
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const first_args a) {
+    __shared__ yk_half lut[256];
+    __shared__ unsigned smx;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int P = a.Ho * a.Wo, wg_per_img = P >> 8;
+    const int b = blockIdx.x / wg_per_img, pix0 = (blockIdx.x - b * wg_per_img) << 8;
+    if (tid < 64) {
+        unsigned m = tid < YK_MAXP ? a.img_max[b * YK_MAXP + tid] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if (tid == 0) smx = m;
+    }
+    __syncthreads();
+    lut[tid] = (yk_half)((float)tid / (float)smx);
+    const int fr = lane & 15, q = lane >> 4, nl4 = q * 4;
+    half8 wf[2];
+    float4 sc[2], bs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        wf[j] = *reinterpret_cast<const half8 *>(a.wm + (j * 16 + fr) * 32 + q * 8);
+        sc[j] = *reinterpret_cast<const float4 *>(a.scale + j * 16 + nl4);
+        bs[j] = *reinterpret_cast<const float4 *>(a.bias + j * 16 + nl4);
+    }
+    const uint32_t img_bytes = (uint32_t)a.Hi * a.Wi * 3u, rowb = (uint32_t)a.Wi * 3u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.in + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 d8[4];
+    uint32_t b9[4][3], shl[4], nval[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int p = pix0 + (wid * 4 + t) * 16 + fr;
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        const int iy0 = oy * a.stride - a.pad_t, s = (ox * a.stride - a.pad_l) * 3;      // s: first byte of the 9 in a tap row
+        // the 8-byte load is clamped into the row: left of it (padding) a shift left brings zeros in, at the row's end a shift
+        // right drops the bytes that would belong to the next row - and the load never runs past the image (bounds check)
+        const int ld = min(max(s, 0), (int)rowb - 8);
+        shl[t] = (uint32_t)((ld - s) * 8);                                                 // > 0: shift left, < 0 (as int): shift right
+        nval[t] = (uint32_t)max(min((int)rowb - s, 9), 0);                                // bytes of the 9 that lie inside the row
+        const int iy = iy0 + q;
+        const bool rowok = q < 3 && (unsigned)iy < (unsigned)a.Hi;
+        d8[t] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, rowok ? (uint32_t)iy * rowb + (uint32_t)ld : YK_OOB, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iyr = iy0 + r;
+            const bool ok = q == 3 && (unsigned)iyr < (unsigned)a.Hi && s + 8 >= 0 && nval[t] == 9u;
+            b9[t][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, ok ? (uint32_t)iyr * rowb + (uint32_t)(s + 8) : YK_OOB, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        unsigned long long v = ((unsigned long long)d8[t][1] << 32) | d8[t][0];
+        const int sh = (int)shl[t];
+        v = sh >= 0 ? (v << sh) : (v >> (-sh));                                            // zero padding on either side
+        if (q == 3) v = (unsigned long long)(b9[t][0] | (b9[t][1] << 8) | (b9[t][2] << 16));
+        half8 xf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = lut[(unsigned)(v >> (8 * j)) & 255u];
+        if (q == 3) {                                                                      // k = 27..31 are padding, not LUT[0]
+#pragma unroll
+            for (int j = 3; j < 8; ++j) xf[j] = (yk_half)0.f;
+        }
+        const int p = pix0 + (wid * 4 + t) * 16 + fr;
+        yk_half *o = a.out + ((size_t)b * P + p) * a.outp;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf, acc, 0, 0, 0);
+            const int n = j * 16 + nl4;
+            if (n < a.outp) {
+                const half4 h = {(yk_half)yk_actf(acc[0] * sc[j].x + bs[j].x, a.slope, a.cap), (yk_half)yk_actf(acc[1] * sc[j].y + bs[j].y, a.slope, a.cap),
+                                 (yk_half)yk_actf(acc[2] * sc[j].z + bs[j].z, a.slope, a.cap), (yk_half)yk_actf(acc[3] * sc[j].w + bs[j].w, a.slope, a.cap)};
+                *reinterpret_cast<half4 *>(o + n) = h;
+            }
+        }
+    }
+}
+
 int yk_launch_first(const first_args &a, hipStream_t st) {
+    static const bool mfma_on = getenv("YK_STEM_MFMA") ? getenv("YK_STEM_MFMA")[0] != '0' : true;
+    if (mfma_on && !a.in_f32 && a.wm && a.Cout <= 32 && a.outp % 4 == 0 && (a.Ho * a.Wo) % 256 == 0 &&
+        (size_t)a.Hi * a.Wi * 3 < YK_OOB) {
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)(a.B * ((a.Ho * a.Wo) >> 8))), dim3(256), 0, st, a);
+        return YK_OK;
+    }
     dim3 grid((a.Ho * a.Wo + 255) / 256, a.B);
     switch (a.Cout) {
     case 16: hipLaunchKernelGGL(first_conv_kernel<16>, grid, dim3(256), 0, st, a); break;

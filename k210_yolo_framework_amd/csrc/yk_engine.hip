@@ -306,6 +306,16 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             f.Hi = X.h; f.Wi = X.w; f.Ho = Y.h; f.Wo = Y.w;
             f.stride = o[YK_F_STRIDE]; f.pad_t = o[YK_F_PAD_T]; f.pad_l = o[YK_F_PAD_L];
             f.Cout = co; f.outp = Y.cp; f.w = (const float *)dw_;
+            if (co <= 32) {                                    // weights again, in the MFMA stem's k order
+                std::vector<uint16_t> wm(32 * 32, 0);
+                for (int n = 0; n < co; ++n)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int j = 0; j < 9; ++j)
+                            wm[(size_t)n * 32 + (j < 8 ? ky * 8 + j : 24 + ky)] = f2h_bits(blob[o[YK_F_W_OFF] + (size_t)n * 27 + ky * 9 + j]);
+                void *dm;
+                if ((rc = upload(p, &dm, wm.data(), wm.size() * 2))) return fail(rc);
+                f.wm = (const yk_half *)dm;
+            }
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &f.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &f.bias))) return fail(rc);
             f.act = o[YK_F_ACT]; f.alpha = alpha; f.out = Y.d;

@@ -106,6 +106,8 @@ int yk_ref_forward_ex(const int32_t *ops, int n_ops, const int32_t *tensors, int
         size_t in_elems = (size_t)batch * T[id].h * T[id].w * T[id].c;
         T[id].d = (float *)malloc(sizeof(float) * in_elems);
         memcpy(T[id].d, in_ptrs[i], sizeof(float) * in_elems);
+        if (emulate_f16) /* the normalised image is stored in fp16 like every other activation (idempotent for the rest) */
+            for (size_t j = 0; j < in_elems; ++j) T[id].d[j] = f16_round(T[id].d[j]);
     }
 
     int rc = 0;

@@ -117,10 +117,17 @@ def test_u8_and_f32_entry_points_agree():
     spec = ns.yolo_mobilev1((64, 96, 3), 3, 20, alpha=0.75)
     w = spec.init_weights(seed=4)
     frames = np.random.default_rng(2).integers(0, 200, (2, 64, 96, 3), dtype=np.uint8)   # max < 255: LUT matters
-    a, _, _ = _run_plan(spec, w, x_u8=frames)
-    b, _, _ = _run_plan(spec, w, x_f32=oracle.normalise_u8(frames))
+    stem = spec.ops[0]['out']
+    a, ma, _ = _run_plan(spec, w, x_u8=frames, want=[stem])
+    b, mb, _ = _run_plan(spec, w, x_f32=oracle.normalise_u8(frames), want=[stem])
+    # u8 frames take the MFMA stem, fp32 images the VALU stem: same fp16 inputs and weights, different fp32 summation order.
+    # The stem outputs may therefore differ by one fp16 ulp in a few elements ...
+    sa, sb = ma[stem].astype(np.float32), mb[stem].astype(np.float32)
+    ulp = np.maximum(np.abs(sb), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(sa - sb) <= ulp).all() and (sa != sb).mean() < 0.02, ((sa != sb).mean(), np.abs(sa - sb).max())
+    # ... and the network outputs agree like any two evaluations under the fp16 storage rule
     for x, y in zip(a, b):
-        np.testing.assert_array_equal(x, y)
+        _check('u8 vs f32 entry', x, y, TOL_EMU)
 
 
 def test_batch_smaller_than_max_batch_and_rerun():
