@@ -216,6 +216,13 @@ def main():
             ach = alg_flops / t_dom / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None}
+        # HBM bytes of that launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+        # tools/one_step.py + tools/profiles_post.py; counters cannot be collected from inside this process)
+        try:
+            prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')))
+            roof['traffic'] = prof.get(f'{dom}:{name}')
+        except Exception:
+            pass
         roof.update({'kernel': name, 'avg_us': round(float(ms[dom]) * 1e3, 2),
                      'sum_kernels_us': round(float(ms.sum()) * 1e3, 1),
                      'per_kernel_us': {f'{i}:{launches[i][0]}': round(float(ms[i]) * 1e3, 2) for i in range(len(ms))}})
