@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__
     const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
     const uint8_t *p = f + (size_t)b * per_image;
     unsigned m = 0;
-    const size_t t = (size_t)j * 256 + tid, nth = (size_t)YK_MAXP * 256;
+    const size_t t = (size_t)j * 256 + tid, nth = (size_t)gridDim.x * 256;
     if (vec_ok) {
         const uint4 *q = reinterpret_cast<const uint4 *>(p);
         const size_t n16 = per_image / 16;
@@ -1063,7 +1063,8 @@ __global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__
 
 int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st) {
     const int vec_ok = (per_image % 16 == 0) && ((uintptr_t)frames % 16 == 0);
-    hipLaunchKernelGGL(u8_max_kernel, dim3(YK_MAXP, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
+    static const int parts = getenv("YK_MAXP_RT") ? std::max(1, std::min(YK_MAXP, atoi(getenv("YK_MAXP_RT")))) : YK_MAXP;   // unused slots stay 0
+    hipLaunchKernelGGL(u8_max_kernel, dim3(parts, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
     return YK_OK;
 }
 
