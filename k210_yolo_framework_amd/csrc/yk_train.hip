@@ -140,7 +140,7 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
     if (tiles < 512 && nk >= 8) {             // small grids (weight gradients, late 7x10 / 14x20 layers): fill the 256 CUs with K slices
         s = (int)std::min<long>((1024 + tiles - 1) / tiles, nk / 4);
         if (s < 1) s = 1;
-        if (s > 256) s = 256;
+        if (s > 64) s = 64;                    // the finishing pass walks the slabs serially
     }
     g.splitk = s;
     g.ws = nullptr;
@@ -261,33 +261,66 @@ extern "C" int yk_col2im3x3_f32(const float *col, int B, int Hi, int Wi, int C, 
 // --------------------------------------------------------------------------------------------------------
 // depthwise 3x3, NHWC fp32; weights [9][C]
 // --------------------------------------------------------------------------------------------------------
+// V consecutive channels per thread (V = 4 when C % 4 == 0: one 16-byte access instead of four 4-byte ones)
+template <int V>
+__device__ __forceinline__ void ldv(const float *p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = p[k];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float *p, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) p[k] = v[k];
+    }
+}
+
+template <int V>
 __global__ void __launch_bounds__(256) dw_fwd_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ w,
                                                      float *__restrict__ y) {
-    const size_t total = (size_t)q.B * q.Ho * q.Wo * q.C;
+    const int CV = q.C / V;
+    const size_t total = (size_t)q.B * q.Ho * q.Wo * CV;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % q.C);
-    const size_t m = i / q.C;
+    const int c = (int)(i % CV) * V;
+    const size_t m = i / CV;
     const int ox = (int)(m % q.Wo), oy = (int)((m / q.Wo) % q.Ho), b = (int)(m / ((size_t)q.Wo * q.Ho));
-    float s = 0.f;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int iy = oy * q.stride - q.pad_t + t / 3, ix = ox * q.stride - q.pad_l + t % 3;
-        if ((unsigned)iy < (unsigned)q.Hi && (unsigned)ix < (unsigned)q.Wi)
-            s += x[(((size_t)b * q.Hi + iy) * q.Wi + ix) * q.C + c] * w[t * q.C + c];
+        if ((unsigned)iy < (unsigned)q.Hi && (unsigned)ix < (unsigned)q.Wi) {
+            float xv[V], wv[V];
+            ldv<V>(x + (((size_t)b * q.Hi + iy) * q.Wi + ix) * q.C + c, xv);
+            ldv<V>(w + t * q.C + c, wv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += xv[k] * wv[k];
+        }
     }
-    y[i] = s;
+    stv<V>(y + m * q.C + c, s);
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) dw_bwd_data_kernel(conv_geom q, const float *__restrict__ dy, const float *__restrict__ w,
                                                           float *__restrict__ dx) {
-    const size_t total = (size_t)q.B * q.Hi * q.Wi * q.C;
+    const int CV = q.C / V;
+    const size_t total = (size_t)q.B * q.Hi * q.Wi * CV;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % q.C);
-    const size_t p = i / q.C;
+    const int c = (int)(i % CV) * V;
+    const size_t p = i / CV;
     const int ix = (int)(p % q.Wi), iy = (int)((p / q.Wi) % q.Hi), b = (int)(p / ((size_t)q.Wi * q.Hi));
-    float s = 0.f;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int ny = iy + q.pad_t - ky;
@@ -300,10 +333,14 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(conv_geom q, const flo
             if (nx < 0 || nx % q.stride) continue;
             const int ox = nx / q.stride;
             if (ox >= q.Wo) continue;
-            s += dy[(((size_t)b * q.Ho + oy) * q.Wo + ox) * q.C + c] * w[(ky * 3 + kx) * q.C + c];
+            float gv[V], wv[V];
+            ldv<V>(dy + (((size_t)b * q.Ho + oy) * q.Wo + ox) * q.C + c, gv);
+            ldv<V>(w + (ky * 3 + kx) * q.C + c, wv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += gv[k] * wv[k];
         }
     }
-    dx[i] = s;
+    stv<V>(dx + p * q.C + c, s);
 }
 
 // Column-sum finish shared by every two-stage reduction here: one wavefront per output element, lanes stride over the
@@ -409,7 +446,8 @@ extern "C" int yk_dw3x3_fwd_f32(const float *x, const float *w, int B, int Hi, i
                                 int pad_l, float *y, void *stream) {
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     const size_t total = (size_t)B * Ho * Wo * C;
-    hipLaunchKernelGGL(dw_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, x, w, y);
+    if (C % 4 == 0) hipLaunchKernelGGL(dw_fwd_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, x, w, y);
+    else hipLaunchKernelGGL(dw_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, x, w, y);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
@@ -417,7 +455,8 @@ extern "C" int yk_dw3x3_bwd_data_f32(const float *dy, const float *w, int B, int
                                      int pad_t, int pad_l, float *dx, void *stream) {
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     const size_t total = (size_t)B * Hi * Wi * C;
-    hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, dy, w, dx);
+    if (C % 4 == 0) hipLaunchKernelGGL(dw_bwd_data_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, dy, w, dx);
+    else hipLaunchKernelGGL(dw_bwd_data_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, dy, w, dx);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
@@ -506,7 +545,7 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(const float *__restri
 // one wavefront per channel folds the chunk partials
 __global__ void __launch_bounds__(256) bn_stats_finish_kernel(const double *__restrict__ partial, int chunks, int C, double invM, float eps,
                                                               float *__restrict__ mean, float *__restrict__ invstd,
-                                                              float *__restrict__ var_out) {
+                                                              float *__restrict__ mm, float *__restrict__ mv, float mom) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double a = 0, b = 0;
@@ -522,7 +561,10 @@ __global__ void __launch_bounds__(256) bn_stats_finish_kernel(const double *__re
         if (var < 0) var = 0;
         mean[c] = (float)mu;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (var_out) var_out[c] = (float)var;
+        if (mm && mv) {                                  // keras: moving = moving*momentum + batch*(1-momentum)
+            mm[c] = mm[c] * mom + (float)mu * (1.f - mom);
+            mv[c] = mv[c] * mom + (float)var * (1.f - mom);
+        }
     }
 }
 __global__ void __launch_bounds__(256) bn_bwd_finish_kernel(const float *__restrict__ partial, int chunks, int C, float *__restrict__ dbeta,
@@ -541,31 +583,38 @@ __global__ void __launch_bounds__(256) bn_bwd_finish_kernel(const float *__restr
         if (dgamma) dgamma[c] = b;
     }
 }
+template <int V>
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float *__restrict__ z, size_t total, int C, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, int act, float alpha, float *__restrict__ y) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= total) return;
     const int c = (int)(i % C);
-    y[i] = t_act(gamma[c] * (z[i] - mean[c]) * invstd[c] + beta[c], act, alpha);
+    float zv[V], mu[V], is[V], ga[V], be[V], o[V];
+    ldv<V>(z + i, zv); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga); ldv<V>(beta + c, be);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = t_act(ga[k] * (zv[k] - mu[k]) * is[k] + be[k], act, alpha);
+    stv<V>(y + i, o);
 }
+template <int V>
 __global__ void __launch_bounds__(256) bn_apply_bwd_kernel(const float *__restrict__ z, const float *__restrict__ dy, size_t total, int C,
                                                            float invM, const float *__restrict__ mean, const float *__restrict__ invstd,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
                                                            const float *__restrict__ dbeta, const float *__restrict__ dgamma, int act,
                                                            float alpha, float *__restrict__ dz) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= total) return;
     const int c = (int)(i % C);
-    const float xh = (z[i] - mean[c]) * invstd[c];
-    const float g = dy[i] * t_act_grad(gamma[c] * xh + beta[c], act, alpha);
-    dz[i] = gamma[c] * invstd[c] * (g - dbeta[c] * invM - xh * dgamma[c] * invM);
-}
-__global__ void __launch_bounds__(256) moving_update_kernel(float *mm, float *mv, const float *mean, const float *var, int C, float mom) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    mm[c] = mm[c] * mom + mean[c] * (1.f - mom);           // keras: moving = moving*momentum + batch*(1-momentum)
-    mv[c] = mv[c] * mom + var[c] * (1.f - mom);
+    float zv[V], gy[V], mu[V], is[V], ga[V], be[V], db[V], dg[V], o[V];
+    ldv<V>(z + i, zv); ldv<V>(dy + i, gy); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga); ldv<V>(beta + c, be);
+    ldv<V>(dbeta + c, db); ldv<V>(dgamma + c, dg);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float xh = (zv[k] - mu[k]) * is[k];
+        const float g = gy[k] * t_act_grad(ga[k] * xh + be[k], act, alpha);
+        o[k] = ga[k] * is[k] * (g - db[k] * invM - xh * dg[k] * invM);
+    }
+    stv<V>(dz + i, o);
 }
 
 static int bn_chunking(size_t M, int C, int *rows_per_chunk, int *cwl) {
@@ -587,19 +636,19 @@ extern "C" int yk_bn_train_fwd_f32(const float *z, long long M, int C, const flo
     char *ws = (char *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
     if (!ws) return YK_ERR_NOMEM;
     double *partial = (double *)ws;
-    float *var = (float *)(ws + sizeof(double) * (size_t)chunks * 2 * C);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_colreduce_kernel<true>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, (const float *)nullptr,
                        (size_t)M, C, rpc, cwl, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
                        0.f, (void *)partial);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const double *)partial, chunks, C, 1.0 / (double)M, eps,
-                       save_mean, save_invstd, var);
+                       save_mean, save_invstd, moving_mean, moving_var, momentum);
     const size_t total = (size_t)M * C;
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
-                       (const float *)save_invstd, gamma, beta, act, alpha, y);
-    if (moving_mean && moving_var)
-        hipLaunchKernelGGL(moving_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, moving_mean, moving_var, (const float *)save_mean,
-                           (const float *)var, C, momentum);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
+                           (const float *)save_invstd, gamma, beta, act, alpha, y);
+    else
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
+                           (const float *)save_invstd, gamma, beta, act, alpha, y);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
@@ -618,8 +667,12 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
                        save_mean, save_invstd, gamma, beta, act, alpha, (void *)partial);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const float *)partial, chunks, C, dbeta, dgamma);
     const size_t total = (size_t)M * C;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, dy, total, C, 1.f / (float)M, save_mean,
-                       save_invstd, gamma, beta, (const float *)dbeta, (const float *)dgamma, act, alpha, dz);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(bn_apply_bwd_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, z, dy, total, C, 1.f / (float)M, save_mean,
+                           save_invstd, gamma, beta, (const float *)dbeta, (const float *)dgamma, act, alpha, dz);
+    else
+        hipLaunchKernelGGL(bn_apply_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, dy, total, C, 1.f / (float)M, save_mean,
+                           save_invstd, gamma, beta, (const float *)dbeta, (const float *)dgamma, act, alpha, dz);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
