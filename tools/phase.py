@@ -61,4 +61,5 @@ for k in ids:
 conc = np.array(conc)
 print('  per-CU: WGs %.1f, max concurrent WGs median %d, time-avg concurrent %.2f' % (np.mean(per_cu), np.median(conc[:, 0]), conc[:, 1].mean()))
 gaps = np.array(gaps) / 100.0
-print('  gap between a WG end (stamp6) and the next WG start on the same CU: median %.2f us, p10 %.2f, p90 %.2f' % (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90)))
+if len(gaps):
+    print('  gap between a WG end (stamp6) and the next WG start on the same CU: median %.2f us, p10 %.2f, p90 %.2f' % (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90)))
