@@ -120,6 +120,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay a captured HIP graph instead of launching eagerly '
                     '(measured: no gain, the step is GPU-bound; kept as an option)')
+    ap.add_argument('--streams', type=int, default=3, help='independent batches in flight: step i runs on stream i %% S with its own plan, '
+                    'outputs and decode scratch (consecutive steps are independent batches)')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
     args = ap.parse_args()
@@ -150,9 +152,23 @@ def main():
     frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
     outs = plan.outputs()
 
+    S = max(1, args.streams)
+    plans = [plan] + [engine.Plan(spec, weights, max_batch=B, device=local) for _ in range(S - 1)]
+    outs_s = [p_.outputs() for p_ in plans]
+    streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
+    for st_ in streams[1 if S == 1 else 0:]:
+        st_.wait_stream(torch.cuda.current_stream())          # frames / weights were produced on the default stream
+    tick = [0]
+
     def step():
-        plan.run_u8(frames)
-        return engine.decode_py(cfg, outs, B, None, 0.7, 0.5)
+        i = tick[0] % S
+        tick[0] += 1
+        if S == 1:
+            plan.run_u8(frames)
+            return engine.decode_py(cfg, outs, B, None, 0.7, 0.5)
+        with torch.cuda.stream(streams[i]):
+            plans[i].run_u8(frames)
+            return engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -167,23 +183,36 @@ def main():
     # once as a HIP graph and replayed (same kernels, same work).
     graph = None
     if args.graph:
-        try:
-            cap_stream = torch.cuda.Stream()
-            cap_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap_stream):
-                step()
-                cap_stream.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=cap_stream):
-                    g_dets, g_counts = step()
-            torch.cuda.current_stream().wait_stream(cap_stream)
-            for _ in range(3):
-                graph.replay()
+        try:                                         # one graph per in-flight batch, captured on (and replayed to) its own stream
+            graphs = []
+            for i in range(S):
+                st_i = streams[i] if S > 1 else torch.cuda.Stream()
+                st_i.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st_i):
+                    plans[i].run_u8(frames)
+                    engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
+                    st_i.synchronize()
+                    g_i = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_i, stream=st_i):
+                        plans[i].run_u8(frames)
+                        keep = engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
+                graphs.append((g_i, st_i, keep))
             torch.cuda.synchronize()
+
+            def replay():
+                i = tick[0] % S
+                tick[0] += 1
+                g_i, st_i, _ = graphs[i]
+                with torch.cuda.stream(st_i):
+                    g_i.replay()
+            for _ in range(2 * S):
+                replay()
+            torch.cuda.synchronize()
+            graph = replay
         except Exception as e:   # capture is an optimisation of the launch path only
             print(f'[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
             graph = None
-    run = graph.replay if graph is not None else step
+    run = graph if graph is not None else step
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,6 +226,21 @@ def main():
         elapsed = shard.max_over_ranks(elapsed, dist, device='cuda')
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    # the same step with ONE batch in flight (its latency), for reference
+    single_ms = None
+    if S > 1:
+        n1 = min(args.steps, 100)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(5):
+                plans[0].run_u8(frames)
+                engine.decode_py(cfg, outs_s[0], B, None, 0.7, 0.5)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(n1):
+                plans[0].run_u8(frames)
+                engine.decode_py(cfg, outs_s[0], B, None, 0.7, 0.5)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t2) / n1 * 1e3
 
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream
@@ -237,6 +281,8 @@ def main():
                                    '20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
                        'launch_mode': 'hip-graph replay' if graph is not None else 'eager',
+                       'batches_in_flight': S, 'one_batch_in_flight_ms_per_step': round(single_ms, 4) if single_ms else round(ms_per_step, 4),
+                       'one_batch_in_flight_images_per_sec': round(world * B / ((single_ms or ms_per_step) * 1e-3), 1),
                        'algorithmic_GB_per_step': round(tot_bytes / 1e9, 4), 'algorithmic_GFLOP_per_step': round(tot_flops / 1e9, 2),
                        'parallelism': f'image-sharded x{world}, no collective'},
             'roofline': roof,
