@@ -295,3 +295,48 @@ def letterbox_u8(frames, dst_hw, stream=None):
     _check(lib().yk_letterbox_u8(_ptr(frames), C.c_int(B), C.c_int(sh), C.c_int(sw), _ptr(out), C.c_int(out.shape[1]),
                                  C.c_int(out.shape[2]), _stream(stream)), 'yk_letterbox_u8')
     return out
+
+
+class Pipeline:
+    """Several independent batches in flight on one GPU (the kpu_run_kmodel(async)+callback shape of main.c:303-311, widened).
+
+    One batch alone leaves CUs idle: a step is ~24 dependent launches, most of them a single round of <= 256 workgroups.
+    `depth` plans, each with its own outputs / split-K slabs, on `depth` HIP streams (decode scratch is per stream inside the
+    library) let the GPU interleave workgroups of different batches; nothing is shared between them but the weight values.
+    submit() returns at once; the returned (dets, counts) tensors belong to that slot's stream until the slot is reused
+    `depth` submits later, so consume them (or call `wait`) before that."""
+
+    def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None):
+        import torch
+        require_gpu()
+        self.depth = max(1, int(depth))
+        self.spec, self.max_batch = spec, int(max_batch)
+        self.plans = [Plan(spec, weights, max_batch=max_batch, device=device) for _ in range(self.depth)]
+        self.outs = [p.outputs() for p in self.plans]
+        cur = torch.cuda.current_stream()
+        self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
+        for s in self.streams:
+            s.wait_stream(cur)
+        self.cfg = make_decode_cfg(anchors, spec.class_num, spec.in_hw, spec.out_hw())
+        self._n = 0
+
+    def submit(self, frames_u8, image_hw=None, obj_thresh: float = 0.7, iou_thresh: float = 0.5, max_out: int = 30):
+        """frames_u8: cuda uint8 [B,H,W,3] (must stay alive until the results are consumed).  -> (dets, counts, stream)."""
+        import torch
+        i = self._n % self.depth
+        self._n += 1
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream())         # the frames may have been produced on the caller's stream
+        with torch.cuda.stream(st):
+            self.plans[i].run_u8(frames_u8)
+            dets, counts = decode_py(self.cfg, self.outs[i], frames_u8.shape[0], image_hw, obj_thresh, iou_thresh, max_out)
+        return dets, counts, st
+
+    def wait(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        self.wait()
+        for p in self.plans:
+            p.close()

@@ -140,3 +140,37 @@ def test_baseline_config3_tiny_yolo_416_end_to_end():
         assert np.array_equal(d[b, :c[b], 5], rd[b][0][:, 5])
         np.testing.assert_allclose(d[b, :c[b], :5], rd[b][0][:, :5], rtol=1e-5, atol=2e-3)
     plan.close()
+
+
+def test_pipeline_three_batches_in_flight_equal_one_at_a_time():
+    """engine.Pipeline: different batches interleaved on 3 streams give exactly the detections of the same batches run alone."""
+    import torch
+    from k210_yolo_framework_amd import engine, netspec as ns
+    from k210_yolo_framework_amd.helper import VOC_ANCHORS
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=1)
+    B, N = 16, 9
+    g = torch.Generator(device='cuda').manual_seed(5)
+    frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g) for _ in range(N)]
+    plan = engine.Plan(spec, w, max_batch=B)
+    cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
+    ref = []
+    for f in frames:
+        plan.run_u8(f)
+        d, c = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)
+        torch.cuda.synchronize()
+        ref.append((d.cpu().numpy().copy(), c.cpu().numpy().copy()))
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=3)
+    for rounds in range(3):                                    # several passes: slots are reused
+        got = [pipe.submit(f) for f in frames[:3]] if rounds == 0 else None
+        res = []
+        for k in range(0, N, 3):
+            batch = [pipe.submit(f) for f in frames[k:k + 3]]
+            pipe.wait()
+            res += [(d.cpu().numpy(), c.cpu().numpy()) for d, c, _ in batch]
+        for (d, c), (rd, rc) in zip(res, ref):
+            assert np.array_equal(c, rc)
+            for b in range(B):
+                assert np.array_equal(d[b, :c[b]], rd[b, :rc[b]])
+    pipe.close()
+    plan.close()
