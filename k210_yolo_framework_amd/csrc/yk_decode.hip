@@ -206,36 +206,122 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             },
             [](int) {});
     } else {
-        // overflow path: in place on the (scratch) score plane; dead = -INF
-        while (kept < max_out) {
-            float best = -INFINITY;
-            int bidx = 0x7fffffff, bpos = -1;
-            for (int i = lane; i < ntot; i += 64) {
-                float v = sc[i];
-                if (v >= obj_thresh && v > -INFINITY && (bpos < 0 || v > best)) {
-                    best = v;
-                    bidx = i;
-                    bpos = i;
+        // More candidates than the LDS holds (degenerate inputs: saturated logits).  Greedy NMS only ever needs the candidates
+        // in descending (score, -index) order, and a candidate's fate depends only on the boxes selected before it - so the
+        // list is processed in CHUNKS of at most YK_NMS_MAXC consecutive keys: find a key interval [lo, hi) holding <= MAXC
+        // candidates by bisection on the 64-bit key (score bits, ~index) with counting passes over the score plane, gather it
+        // into LDS, drop what the boxes selected so far suppress, run the LDS greedy on the rest, continue below lo.
+        // Exact, and ~12 coalesced passes per chunk instead of two passes per selected box (the old in-place loop: 10 ms on
+        // 10 647 boxes x 20 classes x 16 images).
+        const unsigned long long key_min = (unsigned long long)__float_as_uint(fmaxf(obj_thresh, 0.f)) << 32;
+        auto key_of = [&](float v, int i) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~i); };
+        auto count_in = [&](unsigned long long lo, unsigned long long hi) {
+            int cl = 0;
+            for (int i0 = 0; i0 < ntot; i0 += 64 * 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    v[u] = (i < ntot) ? sc[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i < ntot && v[u] >= obj_thresh) {
+                        const unsigned long long k = key_of(v[u], i);
+                        cl += (k >= lo && k < hi) ? 1 : 0;
+                    }
                 }
             }
-            yk_wave_argmax(best, bidx, bpos);
-            if (bpos < 0) break;
-            const float4 wb = bx[bpos];
-            __syncthreads();
-            if (lane == 0) {
-                og[kept] = bpos;
-                os[kept] = best;
-                sc[bpos] = -INFINITY;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cl += __shfl_xor(cl, o, 64);
+            return cl;
+        };
+        __shared__ int selg[256];                                 // global indices of the boxes selected so far (this wave only)
+        const int *selp = (max_out <= 256) ? selg : og;
+        unsigned long long hi = ~0ull;
+        while (kept < max_out) {
+            unsigned long long lo = key_min;
+            int cin = count_in(lo, hi);
+            if (cin == 0) break;
+            if (cin > YK_NMS_MAXC) {                               // invariant: count(lo_bad) > MAXC, count(lo_ok) <= MAXC
+                unsigned long long lo_bad = key_min, lo_ok = hi;
+                while (lo_ok - lo_bad > 1ull) {
+                    const unsigned long long mid = lo_bad + ((lo_ok - lo_bad) >> 1);
+                    const int cm = count_in(mid, hi);
+                    if (cm > YK_NMS_MAXC) lo_bad = mid;
+                    else {
+                        lo_ok = mid;
+                        if (cm >= YK_NMS_MAXC / 2) break;          // a half-full chunk is good enough
+                    }
+                }
+                lo = lo_ok;
             }
+            // gather the chunk [lo, hi): scores and indices first, boxes in bulk afterwards (no load inside the ballot chain)
+            __syncthreads();
+            int nc = 0;
+            for (int i0 = 0; i0 < ntot; i0 += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    v[u] = (i < ntot) ? sc[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    bool f = (i < ntot) && (v[u] >= obj_thresh);
+                    if (f) {
+                        const unsigned long long k = key_of(v[u], i);
+                        f = k >= lo && k < hi;
+                    }
+                    const unsigned long long mk = __ballot(f);
+                    const int pos = nc + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (f && pos < YK_NMS_MAXC) {
+                        L.s[pos] = v[u];
+                        L.idx[pos] = i;
+                    }
+                    nc += __popcll(mk);
+                }
+            }
+            __syncthreads();
+            for (int q0 = 0; q0 < nc; q0 += 256) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * 64 + lane;
+                    t[u] = bx[q < nc ? L.idx[q] : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u * 64 + lane;
+                    if (q < nc) L.box[q] = t[u];
+                }
+            }
+            __syncthreads();
+            // candidates overlapping a box selected in an earlier chunk are dead already
+            for (int q = lane; q < nc; q += 64) {
+                const float4 cb = L.box[q];
+                bool dead = false;
+                for (int k = 0; k < kept && !dead; ++k) dead = tf_iou(cb, bx[selp[k]]) > iou_thresh;
+                if (dead) L.s[q] = -INFINITY;
+            }
+            __syncthreads();
+            const int base = kept;
+            kept += yk_wave_greedy_nms(
+                nc, L.s, L.idx, L.box, iou_thresh, max_out - base, [](const float4 &a, const float4 &d) { return tf_iou(d, a); },
+                [&](int rank, int pos) {
+                    if (lane == 0) {
+                        og[base + rank] = L.idx[pos];
+                        os[base + rank] = L.s[pos];
+                        if (base + rank < 256) selg[base + rank] = L.idx[pos];
+                    }
+                },
+                [](int) {});
             __threadfence_block();
             __syncthreads();
-            for (int i = lane; i < ntot; i += 64) {
-                float v = sc[i];
-                if (v >= obj_thresh && v > -INFINITY && tf_iou(bx[i], wb) > iou_thresh) sc[i] = -INFINITY;
-            }
-            __threadfence_block();
-            __syncthreads();
-            ++kept;
+            if (lo == key_min) break;
+            hi = lo;
         }
     }
     if (lane == 0) cnt[b * C + c] = kept;

@@ -98,3 +98,25 @@ def test_no_detections():
     preds = [np.full((2, 7, 10, 3, 25), -9, np.float32), np.full((2, 14, 20, 3, 25), -9, np.float32)]
     dets, counts = _run(preds, ANCHORS, (224, 320), None, 0.7, 0.5)
     assert counts.tolist() == [0, 0]
+
+
+def test_overflow_chunks_ties_and_suppression_carried_across_chunks():
+    """10 647 candidates with IDENTICAL (saturated) scores: order falls to the box index, the first 2 535 boxes are giants that the
+    very first one suppresses, the survivors come from the third scale - so the kernel must walk several LDS chunks in key order and
+    apply the boxes selected in earlier chunks to later ones."""
+    rng = np.random.default_rng(11)
+    preds = [rng.uniform(-1, 1, (2, h, w, 3, 6)).astype(np.float32) for (h, w) in [(13, 13), (26, 26), (52, 52)]]
+    for li, p in enumerate(preds):
+        p[..., 4] = 30.0                      # sigmoid == 1.0 exactly in fp32
+        p[..., 5] = 30.0
+        p[..., 2:4] = 5.0 if li < 2 else -3.0
+    preds[2][1, ..., 5] = rng.uniform(2, 30, preds[2][1, ..., 5].shape)     # image 1: third scale with distinct scores
+    anchors = np.full((3, 3, 2), 0.05)
+    dets, counts = _run(preds, anchors, (416, 416), None, 0.5, 0.5)
+    ref = dr.decode_batch(preds, anchors, (416, 416), (416, 416), 0.5, 0.5)
+    for b in range(2):
+        rd, _ = ref[b]
+        assert counts[b] == len(rd) == 30
+        np.testing.assert_allclose(dets[b, :30, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
+    # image 0: the first box, then third-scale boxes in index order (all scores tie)
+    assert dets[0, 0, 2] - dets[0, 0, 0] > 1000 and (dets[0, 1:30, 2] - dets[0, 1:30, 0] < 5).all()
