@@ -1367,6 +1367,10 @@ __global__ void __launch_bounds__(64 * WM * WN) fused_dwpw_kernel(const igemm_ar
 //   * phase B touches only LDS + MFMA.
 // Requires 768 % (Cin_pitch/8) == 0.
 // -------------------------------------------------------------------------------------
+#ifndef YK_WIDE_ONE
+#define YK_WIDE_ONE 1   /* one depthwise item in flight per thread: 168 -> 116/140 VGPRs.  Measured: +5 % alone (86.7 vs 82 k images/s)
+                           and +7 % with three batches in flight (121 vs 113 k) - the freed registers let other waves co-reside */
+#endif
 template <int WM, int WN, int TM, int WPF>
 __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
     constexpr int NT = 768;
@@ -1418,9 +1422,9 @@ __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
     }
     __syncthreads();                                 // Ws visible
     YK_STAMP(1)
-    for (int p = pl; p < BM; p += 2 * PP) {
+    for (int p = pl; p < BM; p += (YK_WIDE_ONE ? 1 : 2) * PP) {
         u32x4 x0[9], x1[9];
-        const bool two = (p + PP) < BM;
+        const bool two = !YK_WIDE_ONE && (p + PP) < BM;
         dw_issue(a, rs, (uint32_t)min(m0 + p, a.M - 1), (uint32_t)g * 16u, x0);
         if (two) dw_issue(a, rs, (uint32_t)min(m0 + p + PP, a.M - 1), (uint32_t)g * 16u, x1);
         const yk_half *wl = Ws + g * 8;
@@ -1817,7 +1821,9 @@ int yk_igemm_fused_pick(const igemm_args &a) {
         const int ns = (a.N + 191) / 192;
         const int tiles_m = 256 / ns > 0 ? 256 / ns : 1;
         const int tm = ((a.M + tiles_m - 1) / tiles_m + 15) / 16;
-        const bool deep = a.c0p > 192;
+        // 12-deep weight preload (48 VGPRs) helped one batch alone by a hair and costs co-residency: off (124 vs 121 k images/s in flight)
+        static const bool deep_on = getenv("YK_DEEP") ? getenv("YK_DEEP")[0] != '0' : false;
+        const bool deep = deep_on && a.c0p > 192;
         if (!deep) {
             if (tm <= 2) return WIDE_1x12_T2;
             if (tm <= 4) return WIDE_1x12_T4;

@@ -75,11 +75,20 @@ __device__ __forceinline__ float tf_iou(const float4 &i, const float4 &j) {
 }
 
 // grid (C, batch), one wavefront.  sel_g/sel_s: [batch][C][max_out]; cnt: [batch][C]
+// MAXC: LDS capacity in candidates.  1 088 (26 KB) covers the 224x320 heads (1 050 boxes) and leaves the CU's LDS to the conv kernels
+// of other batches in flight; 2 048 (48 KB) otherwise.
+template <int MAXC>
+struct nms_lds {
+    float s[MAXC];
+    int idx[MAXC];
+    float4 box[MAXC];
+};
+template <int MAXC>
 __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_thresh, float iou_thresh, int max_out,
                                                     const float4 *__restrict__ boxes, float *__restrict__ scores_t,
                                                     int *__restrict__ sel_g, float *__restrict__ sel_s,
                                                     int *__restrict__ cnt) {
-    __shared__ yk_cand_lds L;
+    __shared__ nms_lds<MAXC> L;
     const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     float *sc = scores_t + ((size_t)b * C + c) * ntot;
     const float4 *bx = boxes + (size_t)b * ntot;
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             const bool f = (i < ntot) && (sv[u] >= obj_thresh);      // keras_inference.py:116 (>=)
             const unsigned long long m = __ballot(f);
             const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (f && pos < YK_NMS_MAXC) {
+            if (f && pos < MAXC) {
                 L.s[pos] = sv[u];
                 L.idx[pos] = i;
             }
@@ -110,7 +119,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     // boxes of the candidates, fetched in bulk AFTER the scan: a load inside the ballot loop above would put one global
     // round trip on the critical path per unrolled step (measured: 24 serialised latencies, ~40 us of a 53 us kernel)
     {
-        const int nc = min(n, YK_NMS_MAXC);
+        const int nc = min(n, MAXC);
         for (int c0 = 0; c0 < nc; c0 += 256) {
             float4 t[4];
 #pragma unroll
@@ -131,7 +140,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
         // Fast path (the usual case: a few dozen candidates per class).  TF's own formulation: visit the
         // candidates in descending score order and test each against the boxes selected so far.  The selected
         // boxes live one per lane in registers, so a candidate costs one IoU + one ballot: no LDS writes, no barriers.
-        int *ord = reinterpret_cast<int *>(L.box + YK_NMS_MAXC) - 512;   // tail of the box array is free (n <= 512)
+        int *ord = reinterpret_cast<int *>(L.box + MAXC) - 512;   // tail of the box array is free (n <= 512)
         unsigned long long *key = reinterpret_cast<unsigned long long *>(ord) - 512;
         // rank sort on one 64-bit key per candidate: (score bits, ~box index) — scores are >= 0, so the bit pattern orders
         // like the float; ties fall to the lower box index
@@ -195,7 +204,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
                 }
             }
         }
-    } else if (n <= YK_NMS_MAXC) {
+    } else if (n <= MAXC) {
         kept = yk_wave_greedy_nms(
             n, L.s, L.idx, L.box, iou_thresh, max_out, [](const float4 &a, const float4 &d) { return tf_iou(d, a); },
             [&](int rank, int pos) {
@@ -208,7 +217,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     } else {
         // More candidates than the LDS holds (degenerate inputs: saturated logits).  Greedy NMS only ever needs the candidates
         // in descending (score, -index) order, and a candidate's fate depends only on the boxes selected before it - so the
-        // list is processed in CHUNKS of at most YK_NMS_MAXC consecutive keys: find a key interval [lo, hi) holding <= MAXC
+        // list is processed in CHUNKS of at most MAXC consecutive keys: find a key interval [lo, hi) holding <= MAXC
         // candidates by bisection on the 64-bit key (score bits, ~index) with counting passes over the score plane, gather it
         // into LDS, drop what the boxes selected so far suppress, run the LDS greedy on the rest, continue below lo.
         // Exact, and ~12 coalesced passes per chunk instead of two passes per selected box (the old in-place loop: 10 ms on
@@ -244,15 +253,15 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             unsigned long long lo = key_min;
             int cin = count_in(lo, hi);
             if (cin == 0) break;
-            if (cin > YK_NMS_MAXC) {                               // invariant: count(lo_bad) > MAXC, count(lo_ok) <= MAXC
+            if (cin > MAXC) {                               // invariant: count(lo_bad) > MAXC, count(lo_ok) <= MAXC
                 unsigned long long lo_bad = key_min, lo_ok = hi;
                 while (lo_ok - lo_bad > 1ull) {
                     const unsigned long long mid = lo_bad + ((lo_ok - lo_bad) >> 1);
                     const int cm = count_in(mid, hi);
-                    if (cm > YK_NMS_MAXC) lo_bad = mid;
+                    if (cm > MAXC) lo_bad = mid;
                     else {
                         lo_ok = mid;
-                        if (cm >= YK_NMS_MAXC / 2) break;          // a half-full chunk is good enough
+                        if (cm >= MAXC / 2) break;          // a half-full chunk is good enough
                     }
                 }
                 lo = lo_ok;
@@ -277,7 +286,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
                     }
                     const unsigned long long mk = __ballot(f);
                     const int pos = nc + __popcll(mk & ((1ull << lane) - 1ull));
-                    if (f && pos < YK_NMS_MAXC) {
+                    if (f && pos < MAXC) {
                         L.s[pos] = v[u];
                         L.idx[pos] = i;
                     }
@@ -416,8 +425,12 @@ extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pr
     const int total = batch * ntot;
     hipLaunchKernelGGL(decode_py_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a, batch, d_image_hw, boxes,
                        scores_t);
-    hipLaunchKernelGGL(nms_py_kernel, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out,
-                       boxes, scores_t, sel_g, sel_s, cnt);
+    if (ntot <= 1088)
+        hipLaunchKernelGGL(nms_py_kernel<1088>, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out, boxes, scores_t,
+                           sel_g, sel_s, cnt);
+    else
+        hipLaunchKernelGGL(nms_py_kernel<2048>, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out, boxes, scores_t,
+                           sel_g, sel_s, cnt);
     hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(256), (a.C + 1) * sizeof(int), st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
                        d_dets, d_counts);
     YK_HIP(hipGetLastError());
