@@ -122,6 +122,10 @@ def main():
                     '(measured: no gain, the step is GPU-bound; kept as an option)')
     ap.add_argument('--streams', type=int, default=3, help='independent batches in flight: step i runs on stream i %% S with its own plan, '
                     'outputs and decode scratch (consecutive steps are independent batches)')
+    ap.add_argument('--letterbox', action='store_true', help='SURVEY 8(d) variant (ii): 240x320 camera frames, letterboxed on the GPU '
+                    '(yk_letterbox_u8) to the 224x320 network tensor inside the timed step')
+    ap.add_argument('--from-host', action='store_true', help='frames start in pinned host memory and cross PCIe inside the timed step '
+                    '(reported for reference; never the headline value)')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
     args = ap.parse_args()
@@ -151,6 +155,19 @@ def main():
     g = torch.Generator(device='cuda').manual_seed(rank)
     frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
     outs = plan.outputs()
+    cam = None
+    if args.letterbox:
+        cam = torch.randint(0, 256, (B, 240, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
+    host = None
+    if args.from_host:
+        src = cam if cam is not None else frames
+        host = torch.empty(src.shape, dtype=torch.uint8).pin_memory()
+        host.copy_(src)
+
+    def prepare():
+        """-> the [B,224,320,3] u8 network tensor of this step (identity for the headline variant)."""
+        x = host.cuda(non_blocking=True) if host is not None else (cam if cam is not None else frames)
+        return engine.letterbox_u8(x, (224, 320)) if args.letterbox else x
 
     S = max(1, args.streams)
     plans = [plan] + [engine.Plan(spec, weights, max_batch=B, device=local) for _ in range(S - 1)]
@@ -164,10 +181,10 @@ def main():
         i = tick[0] % S
         tick[0] += 1
         if S == 1:
-            plan.run_u8(frames)
+            plan.run_u8(prepare())
             return engine.decode_py(cfg, outs, B, None, 0.7, 0.5)
         with torch.cuda.stream(streams[i]):
-            plans[i].run_u8(frames)
+            plans[i].run_u8(prepare())
             return engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
 
     def sync_all():
@@ -281,7 +298,7 @@ def main():
                                    '20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
                        'launch_mode': 'hip-graph replay' if graph is not None else 'eager',
-                       'batches_in_flight': S, 'one_batch_in_flight_ms_per_step': round(single_ms, 4) if single_ms else round(ms_per_step, 4),
+                       'batches_in_flight': S, 'frames': ('240x320 letterboxed on GPU' if args.letterbox else '224x320 native') + (', from pinned host memory' if args.from_host else ', resident in HBM'), 'one_batch_in_flight_ms_per_step': round(single_ms, 4) if single_ms else round(ms_per_step, 4),
                        'one_batch_in_flight_images_per_sec': round(world * B / ((single_ms or ms_per_step) * 1e-3), 1),
                        'algorithmic_GB_per_step': round(tot_bytes / 1e9, 4), 'algorithmic_GFLOP_per_step': round(tot_flops / 1e9, 2),
                        'parallelism': f'image-sharded x{world}, no collective'},
