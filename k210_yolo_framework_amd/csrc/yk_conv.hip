@@ -725,6 +725,149 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_lin_kernel(const igemm_arg
     igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
 }
 
+// =====================================================================================
+// igemm_dma_kernel: igemm_lin_kernel with the operand tiles filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs,
+// no ds_write pass (13 cycles per wave-instruction, MI355X_MICROARCH.md), half the registers.  A wave-instruction deposits 64 x 16 B
+// at a wave-uniform LDS base + lane*16, i.e. 8 tile rows of BK = 64 halfs, unpadded; bank conflicts of the fragment reads are
+// avoided by the XOR swizzle tools/lds_sim.py derives for a 128-byte pitch (chunk ^= row & 7), applied on BOTH sides: the lane that
+// lands at (row, chunk) fetches global chunk (chunk ^ row&7), the fragment read of logical chunk q goes to (q ^ row&7)
+// (cdna_hip_programming.md rule 21).  Two LDS stages; the DMA of step k+1 flies under the MFMAs of step k and is retired by the
+// vmcnt(0) in front of the barrier that ends the step, so a stage is read one barrier after its DMA was waited for.
+// Measured (conv3x3 256->512, 26x26, B=16): 64x128x64 tile 461 -> 558 TFLOP/s, 64x64x64 438 -> 451; VGPRs 110 -> 44+16, occupancy 4 -> 8.
+// =====================================================================================
+template <int BM, int BN, int WM, int WN, int OUT>
+__global__ void __launch_bounds__(64 * WM * WN) igemm_dma_kernel(const igemm_args a) {
+    constexpr int NW = WM * WN, BK = 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "8-row DMA groups must divide among the waves");
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    constexpr int STAGE = (BM + BN) * BK;                         // halfs
+    yk_half *lds = reinterpret_cast<yk_half *>(yk_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+    const int Ctp = a.c0p + a.c1p;
+    const int taps = a.ks * a.ks;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int per = (nk_all + a.split_k - 1) / a.split_k;
+    const int kt0 = blockIdx.z * per;
+    const int nk = min(per, nk_all - kt0);
+    const int rr = lane >> 3, gc = (lane & 7) ^ rr;               // row inside the 8-row group, global chunk this lane fetches
+
+    uint32_t P0[A_IT], P1[A_IT], rmask[A_IT], wro[B_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = m0 + (wid + it * NW) * 8 + rr;
+        const bool ok = m < a.M;
+        const uint32_t mm = ok ? m : 0;
+        const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * (a.Ho * a.Wo);
+        const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+        const int ry0 = (int)oy * a.stride - a.pad_t, rx0 = (int)ox * a.stride - a.pad_l;
+        P0[it] = b * (uint32_t)(a.Hi * a.Wi * a.c0p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c0p) * 2u + gc * 16u;
+        P1[it] = b * (uint32_t)(a.Hi * a.Wi * a.c1p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c1p - a.c0p) * 2u + gc * 16u;
+        uint32_t msk = 0;
+        for (int t = 0; t < taps; ++t) {
+            const int ky = (a.ks == 3) ? t / 3 : 0, kx = t - ky * a.ks;
+            if (ok && (unsigned)(ry0 + ky) < (unsigned)a.Hi && (unsigned)(rx0 + kx) < (unsigned)a.Wi) msk |= 1u << t;
+        }
+        rmask[it] = msk;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int n = n0 + (wid + it * NW) * 8 + rr;
+        wro[it] = (n < a.N) ? (uint32_t)(n * a.K) * 2u + gc * 16u : YK_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in1 ? a.in1 : a.in0), 0, a.in1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+    const int lim = kt0 + nk;
+    int step = kt0;
+    int tap = (int)yk_div((uint32_t)kt0 * BK, a.fd_ctp);
+    int cin = kt0 * BK - tap * Ctp;
+    auto dma = [&](int stage) {
+        const bool src1 = cin >= a.c0p;
+        const int ky = (a.ks == 3) ? (tap * 11) >> 5 : 0, kx = tap - ky * a.ks;
+        const bool live = (step < lim) && (tap < taps);
+        const uint32_t toff = (uint32_t)((ky * a.Wi + kx) * (src1 ? a.c1p : a.c0p)) * 2u + (uint32_t)cin * 2u;
+        const uint32_t soff = live ? toff : YK_OOB;
+        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
+        yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const uint32_t o = (src1 ? P1[it] : P0[it]) + soff;
+            const uint32_t off = ((rmask[it] >> tap) & 1u) ? o : YK_OOB;
+            lds_ptr_t dst = (lds_ptr_t)(As + (wid + it * NW) * 8 * BK);
+            if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            lds_ptr_t dstb = (lds_ptr_t)(Bs + (wid + it * NW) * 8 * BK);
+            const uint32_t offb = wro[it] + ws;     // a named local: with the sum written inline hipcc's HOST pass silently drops
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, offb, 0, 0, 0);   // the kernel's stub (undefined symbol at load)
+        }
+        ++step;
+        cin += BK;
+        const bool wrap = cin >= Ctp;
+        cin = wrap ? 0 : cin;
+        tap += wrap ? 1 : 0;
+    };
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, sw = fr & 7, fq = lane >> 4;
+    auto compute = [&](int stage) {
+        const yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + fq) ^ sw) * 8;             // swizzled 16-byte chunk of this lane's fragment
+            half8 wf[TN], xf[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * BK + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * BK + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nk > 0) {
+        dma(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this wave's DMA has landed
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            dma((kt + 1) & 1);                                     // next step (zeros past the end) under this step's MFMAs
+            compute(kt & 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+    }
+    igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_dma(const igemm_args &a, hipStream_t st) {
+    constexpr size_t st2 = (size_t)2 * (BM + BN) * 64 * 2, ct = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t ldsd = st2 > ct ? st2 : ct;
+    dim3 g2((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
+    if (ldsd > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_dma_kernel<BM, BN, WM, WN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_dma_kernel<BM, BN, WM, WN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
+            done = true;
+        }
+    }
+    if (a.split_k > 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), g2, dim3(64 * WM * WN), ldsd, st, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0>), g2, dim3(64 * WM * WN), ldsd, st, a);
+    return YK_OK;
+}
+
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
     const size_t total = (size_t)a.M * (a.ldn >> 2);
     dim3 grid((unsigned)((total + 255) / 256));
@@ -750,6 +893,10 @@ static int launch_cfg(const igemm_args &a, hipStream_t st) {
         }
         hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, a);
     };
+    static const bool dma_on = getenv("YK_DMA") ? getenv("YK_DMA")[0] != '0' : true;      // LDS-DMA operand tiles (YK_DMA=0: register staging)
+    if constexpr (UNI_OK && BK == 64 && !F32 && (BM / 8) % (WM * WN) == 0 && (BN / 8) % (WM * WN) == 0) {
+        if (dma_on && uni && !a.up0) return launch_dma<BM, BN, WM, WN>(a, st);
+    }
     static const bool lin_on = getenv("YK_LIN") ? getenv("YK_LIN")[0] != '0' : true;
     constexpr bool LIN_OK = UNI_OK && ((BM * (BK / 8)) % (64 * WM * WN) == 0) && ((BN * (BK / 8)) % (64 * WM * WN) == 0);
     if constexpr (LIN_OK) {
