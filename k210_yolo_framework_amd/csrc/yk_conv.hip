@@ -977,7 +977,10 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     // (loads -> LDS -> barrier -> fragments -> MFMA), so MORE, SMALLER workgroups win: 64x64x64 beats 128x64x32 by 10-15 % and
     // 128x128x64 (1 wave/SIMD) is the slowest everywhere (104x104 64->128: 294 vs 416).  Long reductions therefore take the
     // small tile; short ones keep 128x64, whose per-workgroup fixed cost is amortised over more output.
-    if (a.K >= 512) return (a.N % 128 == 0 && a.N >= 256 && a.K >= 2048 && a.M >= 8192) ? IGEMM_64x128 : IGEMM_64x64;
+    // with LDS-DMA tiles the 64x128x64 config is the fastest wherever it applies (52x52 128->256: 519 vs 460 TFLOP/s for 64x64x64,
+    // 13x13 512->1024: 480 vs 447); the register-staged fallbacks (upsampled input, channel pitch not a multiple of 64) keep 64x64
+    const bool dma_ok = !a.up0 && ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);
+    if (a.K >= 512) return (a.N % 128 == 0 && dma_ok) ? IGEMM_64x128 : IGEMM_64x64;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;
 }
