@@ -81,7 +81,8 @@ struct region_args {
     float scale_w, scale_h;   // (float)net_w / new_w                   (float)
 };
 
-__device__ __forceinline__ float region_logistic(float v) { return 1.f / (1.f + expf(-v)); }
+// every exp of the C path goes through the glibc-identical evaluation (yk_common.h): the reference calls libm on the host
+__device__ __forceinline__ float region_logistic(float v) { return 1.f / (1.f + yk_expf_glibc(-v)); }
 
 // one thread per box; box index bi = n*H*W + loc  (region_layer.c:190)
 __global__ void __launch_bounds__(256) region_decode_kernel(region_args a, const float *__restrict__ in, int batch,
@@ -112,11 +113,11 @@ __global__ void __launch_bounds__(256) region_decode_kernel(region_args a, const
         if (v > top) top = v;
     }
     float total = 0.f;
-    for (int j = 0; j < a.C; ++j) total += expf(cl[j * a.se] - top);
+    for (int j = 0; j < a.C; ++j) total += yk_expf_glibc(cl[j * a.se] - top);
     float *pr = probs + ((size_t)b * nb + bi) * (a.C + 1);
     float best = 0.f;
     for (int j = 0; j < a.C; ++j) {
-        float e = expf(cl[j * a.se] - top) / total;
+        float e = yk_expf_glibc(cl[j * a.se] - top) / total;
         if (o) o[(5 + j) * hw] = e;
         float pj = obj * e;
         pr[j] = (pj > a.threshold) ? pj : 0.f;
@@ -125,8 +126,8 @@ __global__ void __launch_bounds__(256) region_decode_kernel(region_args a, const
     pr[a.C] = best;
     float bx = (col + sx) / a.W;
     float by = (row + sy) / a.H;
-    float bw = expf(tw) * a.anchor[2 * n];
-    float bh = expf(th) * a.anchor[2 * n + 1];
+    float bw = yk_expf_glibc(tw) * a.anchor[2 * n];
+    float bh = yk_expf_glibc(th) * a.anchor[2 * n + 1];
     bx = (float)(((double)bx - a.off_x) / (double)a.ratio_x);
     by = (float)(((double)by - a.off_y) / (double)a.ratio_y);
     bw *= a.scale_w;
