@@ -4,7 +4,7 @@
 #   make build       hipcc --offload-arch=gfx950 -> k210_yolo_framework_amd/csrc/libyolo_hip.so (+ the CPU oracle used by the tests)
 #   make test        CPU suite;  `python -m pytest tests -m gpu` needs an MI355X
 #   make bench       images/sec, yolo_mobilev1-0.75, 32 frames per step (GPUS=N runs one rank per GPU through torchrun)
-#   make inference   MODEL=... DEPTHMUL=... CKPT=weights.npz IMG=picture.jpg
+#   make inference   MODEL=... DEPTHMUL=... CKPT=weights.h5|.npz IMG=picture.jpg
 #   make train       MODEL=... DEPTHMUL=... BATCH=16 MAXEP=10 [SYNTHETIC=256]
 
 PY            ?= python3
@@ -17,7 +17,7 @@ OUTSIZE       ?= 7 10 14 20
 OBJTHRESH     ?= 0.7
 IOUTHRESH     ?= 0.5
 CKPT          ?= ""
-IMG           ?= data/people.jpg
+IMG           ?= data/synthetic_320x224.jpg
 # training only
 BATCH         ?= 32
 MAXEP         ?= 10

@@ -129,6 +129,17 @@ int yk_device_count(void);
 int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
                    const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
                    int device);
+/* The same with a choice of arithmetic (there is no reference counterpart: Keras computes in fp32 on the CPU):
+ *   YK_PRECISION_F16    fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulate — the throughput mode
+ *                       (= yk_plan_create).  Scores drift ~2e-4 mean / ~2e-3 max from the fp32 Keras path.
+ *   YK_PRECISION_F16X2  fp32 activations in HBM, compensated fp16 MFMA operands (x = hi + lo, three MFMAs per product),
+ *                       fp32 accumulate: fp32-class results (the "within 1e-3, indices exact" clause of the north star),
+ *                       no fusion.  Per-image operand scaling: results never depend on the batch mates. */
+#define YK_PRECISION_F16 0
+#define YK_PRECISION_F16X2 1
+int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
+                      const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
+                      int device, int precision);
 void yk_plan_destroy(yk_plan_t *p);
 
 /* kpu_run_kmodel analogue, asynchronous on `stream`.

@@ -132,3 +132,14 @@ int yk_launch_pool(const pool_args &a, hipStream_t st);
 
 // ---- residual add fallback (only when it cannot be fused into a conv epilogue) ------------------
 int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, hipStream_t st);
+
+// ---- "f16x2" precision mode (yk_exact.hip): fp32 activations, compensated fp16 MFMA operands ----------------------
+struct yk_xplan;
+int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors, const float *blob,
+                    size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch);
+void yk_xplan_destroy(yk_xplan *p);
+int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream_t st, hipEvent_t *ev);
+int yk_xplan_output(yk_xplan *p, int idx, float **d_ptr, size_t *bytes, int *h, int *w, int *c);
+int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t dst_elems);
+int yk_xplan_launch_count(const yk_xplan *p);
+int yk_xplan_launch_info(const yk_xplan *p, int i, const char **name, double *flops, double *bytes);

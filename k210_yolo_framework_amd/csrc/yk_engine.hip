@@ -103,6 +103,7 @@ struct yk_plan {
     size_t slab_bytes = 0;
     int in_h = 0, in_w = 0;
     int last_batch = 0;
+    yk_xplan *x = nullptr;       // precision 1 ("f16x2"): the plan lives in yk_exact.hip, everything below forwards to it
 };
 
 static int dev_alloc(yk_plan *p, void **ptr, size_t bytes, bool zero) {
@@ -137,12 +138,19 @@ extern "C" void yk_plan_destroy(yk_plan_t *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *q : p->allocs) (void)hipFree(q);
+    yk_xplan_destroy(p->x);
     delete p;
 }
 
 extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
                               const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
                               int device) {
+    return yk_plan_create_ex(out, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch, device, YK_PRECISION_F16);
+}
+
+extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
+                                 const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
+                                 int device, int precision) {
     if (!out || !ops || !tensors || !blob || !outputs || n_ops <= 0 || n_tensors <= 0 || max_batch <= 0) {
         yk_set_error("yk_plan_create: bad argument");
         return YK_ERR_ARG;
@@ -188,6 +196,16 @@ extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, co
             return fail(YK_ERR_ARG);
         }
         p->outputs.push_back(outputs[i]);
+    }
+    if (precision == YK_PRECISION_F16X2) {
+        rc = yk_xplan_create(&p->x, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch);
+        if (rc) return fail(rc);
+        *out = p;
+        return YK_OK;
+    }
+    if (precision != YK_PRECISION_F16) {
+        yk_set_error("yk_plan_create_ex: unknown precision %d", precision);
+        return fail(YK_ERR_ARG);
     }
     // pass 1: views, use counts, output flags
     for (int i = 0; i < n_ops; ++i) {
@@ -542,6 +560,10 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
     }
     YK_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
+    if (p->x) {
+        p->last_batch = batch;
+        return yk_xplan_run(p->x, d_in, in_f32, batch, st, ev);
+    }
     int li = 0;
     for (launch &l : p->L) {
         int rc = YK_OK;
@@ -605,7 +627,7 @@ extern "C" int yk_plan_profile(yk_plan_t *p, const uint8_t *d_frames, int batch,
         yk_set_error("yk_plan_profile: bad argument");
         return YK_ERR_ARG;
     }
-    const int n = (int)p->L.size();
+    const int n = yk_plan_launch_count(p);
     std::vector<hipEvent_t> ev(2 * n);
     for (auto &e : ev) YK_HIP(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
@@ -637,6 +659,7 @@ extern "C" int yk_get_output(yk_plan_t *p, int idx, float **d_ptr, size_t *bytes
         yk_set_error("yk_get_output: bad index");
         return YK_ERR_ARG;
     }
+    if (p->x) return yk_xplan_output(p->x, idx, d_ptr, bytes, h, w, c);
     const tinfo &t = p->T[p->outputs[idx]];
     if (d_ptr) *d_ptr = t.d32;
     if (bytes) *bytes = (size_t)p->max_batch * t.h * t.w * t.c * sizeof(float);
@@ -650,6 +673,10 @@ extern "C" int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_d
     if (!p || tid <= 0 || tid >= (int)p->T.size() || batch <= 0 || batch > p->max_batch || !h_dst) {
         yk_set_error("yk_debug_read_tensor: bad argument");
         return YK_ERR_ARG;
+    }
+    if (p->x) {
+        YK_HIP(hipSetDevice(p->device));
+        return yk_xplan_read_tensor(p->x, tid, batch, h_dst, dst_elems);
     }
     const tinfo &t = p->T[tid];
     const size_t n = (size_t)batch * t.h * t.w * t.c;
@@ -678,7 +705,7 @@ extern "C" int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_d
 // dev instrumentation: arm phase timestamps for launch `li`, run once (u8 path), copy out [n_wg][8] ticks (100 MHz)
 extern "C" int yk_debug_phase_stamps(yk_plan_t *p, int li, const uint8_t *d_frames, int batch, void *stream,
                                      long long *h_out, int max_wg) {
-    if (!p || li < 0 || li >= (int)p->L.size()) return YK_ERR_ARG;
+    if (!p || p->x || li < 0 || li >= (int)p->L.size()) return YK_ERR_ARG;
     YK_HIP(hipSetDevice(p->device));
     if (!p->d_dbg) {
         int rc = dev_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 8 * 65536, true);
@@ -695,10 +722,20 @@ extern "C" int yk_debug_phase_stamps(yk_plan_t *p, int li, const uint8_t *d_fram
     return YK_OK;
 }
 
-extern "C" int yk_plan_launch_count(const yk_plan_t *p) { return p ? (int)p->L.size() : 0; }
+extern "C" int yk_plan_launch_count(const yk_plan_t *p) { return !p ? 0 : (p->x ? yk_xplan_launch_count(p->x) : (int)p->L.size()); }
 
 extern "C" int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, double *flops_per_image,
                                    double *bytes_per_image) {
+    if (p && p->x) {
+        const char *nm = "";
+        double fl = 0, by = 0;
+        int rc = yk_xplan_launch_info(p->x, i, &nm, &fl, &by);
+        if (rc) return rc;
+        if (name && name_len) snprintf(name, name_len, "%s", nm);
+        if (flops_per_image) *flops_per_image = fl;
+        if (bytes_per_image) *bytes_per_image = by;
+        return YK_OK;
+    }
     if (!p || i < 0 || i >= (int)p->L.size()) return YK_ERR_ARG;
     if (name && name_len) snprintf(name, name_len, "%s", p->L[i].name.c_str());
     if (flops_per_image) *flops_per_image = p->L[i].flops;

@@ -3,8 +3,14 @@
 // translation = ((in_wh - img_wh*scale)/2).astype(int), then
 // skimage.transform.warp(img, AffineTransform(scale, translation).inverse, output_shape=in_hw, order=1,
 //                        mode='constant', cval=0, preserve_range=True).astype('uint8')
-// restated as: out(x,y) = bilinear(in, ((x-tx)/s, (y-ty)/s)) with zero outside, float64 math, truncating cast.
-// skimage 0.15 is third-party and absent: parity unpinned except for the identity case (dog.jpg).
+// restated with skimage's own arithmetic (float64, one rounding per operation; this file is built with -ffp-contract=off):
+//   M = inv(AffineTransform.params) = [[1/s, 0, -(tx*(1/s))], [0, 1/s, -(ty*(1/s))], [0, 0, 1]]   (numpy.linalg.inv of that matrix)
+//   c = M00*x + M02, r = M11*y + M12                                   (_warps_cy._transform_metric)
+//   minr/minc = floor, maxr/maxc = ceil, dr = r - minr, dc = c - minc   (interpolation.pxd bilinear_interpolation)
+//   top = (1-dc)*I[minr,minc] + dc*I[minr,maxc]; bottom likewise on maxr; out = (1-dr)*top + dr*bottom; pixels outside -> cval 0
+//   .astype('uint8') truncation.
+// Pinned: tests/golden/letterbox_golden.npz holds outputs of the real scikit-image for seven source sizes; the kernel, the host
+// mirror (helper.letterbox_bilinear) and the oracle reproduce them bit for bit.
 // The per-image max normalisation that follows (utils.py:405) is fused into the stem conv (yk_run_u8).
 #include "yk_common.h"
 
@@ -14,24 +20,21 @@ __global__ void __launch_bounds__(256) letterbox_u8_kernel(const uint8_t *__rest
     const size_t total = (size_t)batch * dh * dw;
     if (idx >= total) return;
     const int x = (int)(idx % dw), y = (int)((idx / dw) % dh), b = (int)(idx / ((size_t)dw * dh));
-    const double fx = ((double)x - (double)tx) / scale, fy = ((double)y - (double)ty) / scale;
+    const double inv = 1.0 / scale;
+    const double c = inv * (double)x + (-((double)tx * inv)), r = inv * (double)y + (-((double)ty * inv));
+    const double minc_f = floor(c), minr_f = floor(r);
+    const int minc = (int)minc_f, minr = (int)minr_f, maxc = (int)ceil(c), maxr = (int)ceil(r);
+    const double dc = c - minc_f, dr = r - minr_f;
     uint8_t *o = dst + idx * 3;
-    if (!(fx > -1.0 && fx < (double)sw && fy > -1.0 && fy < (double)sh)) {
-        o[0] = o[1] = o[2] = 0;
-        return;
-    }
-    const double x0f = floor(fx), y0f = floor(fy);
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const double ax = fx - x0f, ay = fy - y0f;
     const uint8_t *im = src + (size_t)b * sh * sw * 3;
-    auto px = [&](int yy, int xx, int c) -> double {
-        return (yy >= 0 && yy < sh && xx >= 0 && xx < sw) ? (double)im[((size_t)yy * sw + xx) * 3 + c] : 0.0;
+    auto px = [&](int yy, int xx, int ch) -> double {
+        return (yy >= 0 && yy < sh && xx >= 0 && xx < sw) ? (double)im[((size_t)yy * sw + xx) * 3 + ch] : 0.0;
     };
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double v = px(y0, x0, c) * (1.0 - ay) * (1.0 - ax) + px(y0, x0 + 1, c) * (1.0 - ay) * ax +
-                         px(y0 + 1, x0, c) * ay * (1.0 - ax) + px(y0 + 1, x0 + 1, c) * ay * ax;
-        o[c] = (uint8_t)v;    // astype('uint8'): truncation
+    for (int ch = 0; ch < 3; ++ch) {
+        const double top = (1.0 - dc) * px(minr, minc, ch) + dc * px(minr, maxc, ch);
+        const double bottom = (1.0 - dc) * px(maxr, minc, ch) + dc * px(maxr, maxc, ch);
+        o[ch] = (uint8_t)((1.0 - dr) * top + dr * bottom);    // astype('uint8'): truncation
     }
 }
 

@@ -17,6 +17,7 @@ from . import netspec as ns
 
 LIB_PATH = Path(__file__).resolve().parent / 'csrc' / 'libyolo_hip.so'
 YK_MAX_LAYERS, YK_MAX_ANCHORS = 4, 8
+PRECISIONS = {'f16': 0, 'f16x2': 1}          # YK_PRECISION_F16 / YK_PRECISION_F16X2
 _lib: Optional[C.CDLL] = None
 
 f32p = C.POINTER(C.c_float)
@@ -66,7 +67,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(str(LIB_PATH))
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
-        for fn in ('yk_plan_create', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
+        for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
                    'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
@@ -103,17 +104,26 @@ class _DevView:
     """Zero-copy torch view of library-owned device memory via __cuda_array_interface__."""
 
     def __init__(self, ptr: int, shape, typestr: str, owner):
+        import weakref
         self.__cuda_array_interface__ = {'shape': tuple(int(s) for s in shape), 'typestr': typestr,
                                          'data': (int(ptr), False), 'version': 2}
-        self._owner = owner
+        # weak: torch keeps this object alive inside the tensor's storage deleter, where Python's GC cannot see it; a strong
+        # reference would tie Plan -> views -> storage -> _DevView -> Plan into a cycle that never frees the device memory.
+        # The views are BORROWED (kpu_get_output semantics): they are valid until the plan is closed.
+        self._owner = weakref.ref(owner)
 
 
 class Plan:
     """kpu_load_kmodel analogue (main.c:274): a compiled, device-resident network."""
 
-    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None):
+    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None, precision: str = 'f16'):
+        """precision: 'f16' (fp16 activations, the throughput mode) or 'f16x2' (fp32 activations, compensated fp16 MFMA
+        operands: fp32-class results, see include/yolo_hip.h YK_PRECISION_*)."""
         import torch
         require_gpu()
+        if precision not in PRECISIONS:
+            raise YkError(f'precision {precision!r}: expected one of {sorted(PRECISIONS)}')
+        self.precision = precision
         self.spec = spec
         self.max_batch = int(max_batch)
         self.device = torch.cuda.current_device() if device is None else int(device)
@@ -124,16 +134,24 @@ class Plan:
         outs = np.ascontiguousarray(spec.outputs, np.int32)
         self._h = C.c_void_p()
         L = lib()
-        _check(L.yk_plan_create(C.byref(self._h), self._ops.ctypes.data_as(i32p), C.c_int(len(ops)),
-                                self._tens.ctypes.data_as(i32p), C.c_int(len(tens)), blob.ctypes.data_as(f32p),
-                                C.c_size_t(blob.size), outs.ctypes.data_as(i32p), C.c_int(len(outs)),
-                                C.c_int(self.max_batch), C.c_int(self.device)), 'yk_plan_create')
+        _check(L.yk_plan_create_ex(C.byref(self._h), self._ops.ctypes.data_as(i32p), C.c_int(len(ops)),
+                                   self._tens.ctypes.data_as(i32p), C.c_int(len(tens)), blob.ctypes.data_as(f32p),
+                                   C.c_size_t(blob.size), outs.ctypes.data_as(i32p), C.c_int(len(outs)),
+                                   C.c_int(self.max_batch), C.c_int(self.device), C.c_int(PRECISIONS[precision])), 'yk_plan_create_ex')
         self._out_views = None
 
     def close(self):
+        self._out_views = None
         if getattr(self, '_h', None) and self._h.value:
             lib().yk_plan_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:

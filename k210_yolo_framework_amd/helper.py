@@ -1,15 +1,17 @@
 """Host-side mirror of the reference's `tools/utils.py` API surface for the hot path.
 
-Same names, argument meaning and array shapes as the reference (`Helper`, `tf_xywh_to_all`,
-`tf_xywh_to_grid`, `tf_iou`), with numpy / torch tensors instead of `tf.Tensor`.  The pure-numpy
-members are restated from tools/utils.py (file:line in each docstring); the heavy arithmetic
-(model forward, decode, NMS, loss) is NOT here — it runs in libyolo_hip.so.
+Same names, argument meaning and array shapes as the reference (`Helper`, `tf_xywh_to_all`, `tf_xywh_to_grid`, `tf_iou`,
+`calc_ignore_mask`, `create_loss_fn`), with numpy / torch tensors instead of `tf.Tensor`.  The members are written for this
+code base (vectorised numpy, tables built with broadcasting); each docstring names the reference lines whose BEHAVIOUR it
+reproduces, and tests/test_helper.py pins every one of them with hand-derived known answers.  The heavy arithmetic (model
+forward, decode, NMS, loss) is NOT here — it runs in libyolo_hip.so.
 
-Out of scope: imgaug augmentation, the tf.data pipeline, matplotlib drawing.
+Out of scope: imgaug augmentation, matplotlib drawing.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple, Union
+import os
+from typing import Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -19,136 +21,134 @@ INFO, ERROR, NOTE = '[ INFO  ]', '[ ERROR ]', '[ NOTE  ]'     # tools/utils.py:1
 VOC_ANCHORS = np.array([[[0.76120044, 0.57155991], [0.6923348, 0.88535553], [0.47163042, 0.34163313]],
                         [[0.33340788, 0.70065861], [0.18124964, 0.38986752], [0.08497349, 0.1527057]]], np.float64)
 
+# tools/utils.py:89-105 (data table): 20 VOC colours + 20 more
+_COLORMAP = [(255, 82, 0), (0, 255, 245), (0, 61, 255), (0, 255, 112), (0, 255, 133), (255, 0, 0), (255, 163, 0), (255, 102, 0),
+             (194, 255, 0), (0, 143, 255), (51, 255, 0), (0, 82, 255), (0, 255, 41), (0, 255, 173), (10, 0, 255), (173, 255, 0),
+             (0, 255, 153), (255, 92, 0), (255, 0, 255), (255, 0, 245), (128, 0, 0), (0, 128, 0), (128, 128, 0), (0, 0, 128),
+             (128, 0, 128), (0, 128, 128), (128, 128, 128), (64, 0, 0), (192, 0, 0), (64, 128, 0), (192, 128, 0), (64, 0, 128),
+             (192, 0, 128), (64, 128, 128), (192, 128, 128), (0, 64, 0), (128, 64, 0), (0, 192, 0), (128, 192, 0), (0, 64, 128)]
+
 
 class Helper(object):
-    """tools/utils.py:53-521."""
+    """tools/utils.py:53-521: anchors, grid tables, label encode/decode, image reading and letterboxing, dataset iteration."""
 
     def __init__(self, image_ann: Optional[str], class_num: int, anchors: Union[str, np.ndarray, None],
                  in_hw: Sequence, out_hw: Sequence, validation_split: float = 0.1):
-        self.in_hw = np.array(in_hw)
-        assert self.in_hw.ndim == 2
-        self.out_hw = np.array(out_hw)
-        assert self.out_hw.ndim == 2
+        self.in_hw, self.out_hw = np.asarray(in_hw), np.asarray(out_hw)
+        if self.in_hw.ndim != 2 or self.out_hw.ndim != 2:
+            raise AssertionError('in_hw / out_hw must be [[h, w], ...]')
         self.validation_split = validation_split
-        if image_ann is None:
-            self.train_list = None
-            self.test_list = None
-        else:
-            img_ann_list = np.load(image_ann, allow_pickle=True)
-            num = int(len(img_ann_list) * self.validation_split)
-            self.train_list = img_ann_list[num:]
-            self.test_list = img_ann_list[:num]
-            self.train_total_data = len(self.train_list)
-            self.test_total_data = len(self.test_list)
-        self.grid_wh = (1 / self.out_hw)[:, [1, 0]]                         # utils.py:70
+        self.train_list = self.test_list = None
+        if image_ann is not None:                        # [path, boxes, ...] rows; the head of the list is the validation split
+            rows = np.load(image_ann, allow_pickle=True)
+            n_val = int(len(rows) * validation_split)
+            self.test_list, self.train_list = rows[:n_val], rows[n_val:]
+            self.train_total_data, self.test_total_data = len(self.train_list), len(self.test_list)
+        self.grid_wh = 1.0 / self.out_hw[:, ::-1]        # size of one cell, (w, h) per layer           utils.py:70
         if class_num:
             self.class_num = class_num
         if anchors is not None:
             self.anchors = np.load(anchors) if isinstance(anchors, str) else np.asarray(anchors)
-            self.anchor_number = len(self.anchors[0])
-            self.output_number = len(self.anchors)
+            self.output_number, self.anchor_number = len(self.anchors), len(self.anchors[0])
             self.xy_offset = Helper._coordinate_offset(self.anchors, self.out_hw)
             self.wh_scale = Helper._anchor_scale(self.anchors, self.grid_wh)
-        self.output_shapes = [[None] + list(self.out_hw[i]) + [len(self.anchors[i]), self.class_num + 5]
-                              for i in range(len(self.anchors))]
+        self.output_shapes = [[None, int(hw[0]), int(hw[1]), len(a), self.class_num + 5] for hw, a in zip(self.out_hw, self.anchors)]
         self.batch_size = None
-        self.colormap = [                                                    # utils.py:89-105
-            (255, 82, 0), (0, 255, 245), (0, 61, 255), (0, 255, 112), (0, 255, 133),
-            (255, 0, 0), (255, 163, 0), (255, 102, 0), (194, 255, 0), (0, 143, 255),
-            (51, 255, 0), (0, 82, 255), (0, 255, 41), (0, 255, 173), (10, 0, 255),
-            (173, 255, 0), (0, 255, 153), (255, 92, 0), (255, 0, 255), (255, 0, 245),
-            (128, 0, 0), (0, 128, 0), (128, 128, 0), (0, 0, 128), (128, 0, 128),
-            (0, 128, 128), (128, 128, 128), (64, 0, 0), (192, 0, 0), (64, 128, 0),
-            (192, 128, 0), (64, 0, 128), (192, 0, 128), (64, 128, 128), (192, 128, 128),
-            (0, 64, 0), (128, 64, 0), (0, 192, 0), (128, 192, 0), (0, 64, 128)]
+        self.colormap = list(_COLORMAP)
 
-    # ---- label side (tools/utils.py:140-230) --------------------------------------------------
+    # ---- label side (behaviour of tools/utils.py:140-307) -----------------------------------------
     def _xy_grid_index(self, box_xy: np.ndarray, layer: int):
-        """utils.py:156: floor(xy * (w,h)) -> [idx, idy]."""
-        return np.floor(box_xy * self.out_hw[layer][::-1]).astype('int')
+        """Cell (column, row) that holds a centre given relative to the image (utils.py:156)."""
+        h, w = self.out_hw[layer]
+        return np.floor(np.asarray(box_xy) * (w, h)).astype(int)
 
     @staticmethod
     def _fake_iou(a: np.ndarray, b: np.ndarray):
-        """utils.py:159-188: IoU of two boxes sharing a centre."""
-        a_maxes = a / 2.
-        a_mins = -a_maxes
-        b_maxes = b / 2.
-        b_mins = -b_maxes
-        iner_wh = np.maximum(np.minimum(a_maxes, b_maxes) - np.maximum(a_mins, b_mins), 0.)
-        iner_area = iner_wh[..., 0] * iner_wh[..., 1]
-        s1 = a[..., 0] * a[..., 1]
-        s2 = b[..., 0] * b[..., 1]
-        return iner_area / (s1 + s2 - iner_area)
+        """IoU of boxes (w,h) that share their centre (utils.py:159-188): the overlap is min(w)*min(h)."""
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        overlap = np.clip(np.minimum(a, b), 0.0, None).prod(axis=-1)
+        return overlap / (a.prod(axis=-1) + b.prod(axis=-1) - overlap)
 
     def _get_anchor_index(self, wh: np.ndarray):
-        """utils.py:190-205 -> (layer, anchor) of the best centred-IoU anchor over ALL layers."""
-        iou = Helper._fake_iou(wh, self.anchors)
-        return np.unravel_index(np.argmax(iou), iou.shape)
+        """(layer, anchor) whose shape fits `wh` best over ALL layers (utils.py:190-205)."""
+        table = Helper._fake_iou(wh, self.anchors)
+        return np.unravel_index(int(table.argmax()), table.shape)
 
     def box_to_label(self, true_box: np.ndarray) -> List[np.ndarray]:
-        """utils.py:207-230. true_box [n,5] = [cls,x,y,w,h] image-relative -> L x [h,w,A,5+C] fp32."""
-        labels = [np.zeros((self.out_hw[i][0], self.out_hw[i][1], len(self.anchors[i]), 5 + self.class_num),
-                           dtype='float32') for i in range(self.output_number)]
-        for box in true_box:
-            l, n = self._get_anchor_index(box[3:5])
-            idx, idy = self._xy_grid_index(box[1:3], l)
-            labels[l][idy, idx, n, 0:4] = np.clip(box[1:5], 1e-8, 1.)
-            labels[l][idy, idx, n, 4] = 1.
-            labels[l][idy, idx, n, 5 + int(box[0])] = 1.
-        return labels
+        """[n,5] = [cls,x,y,w,h] (image-relative) -> one [h,w,A,5+C] float32 grid per layer (utils.py:207-230).
+        A box lands in the cell of its centre, at the best-fitting anchor: xywh clipped to [1e-8, 1], conf 1, one-hot class.
+        Boxes are written in order, so a later box in the same slot replaces xywh and ADDS its class bit, like the reference."""
+        grids = [np.zeros((*map(int, self.out_hw[l]), len(self.anchors[l]), 5 + self.class_num), np.float32)
+                 for l in range(self.output_number)]
+        boxes = np.asarray(true_box, float).reshape(-1, 5)
+        if len(boxes):
+            fit = Helper._fake_iou(boxes[:, None, None, 3:5], self.anchors[None])            # [n, L, A]
+            layer, anchor = np.unravel_index(fit.reshape(len(boxes), -1).argmax(1), fit.shape[1:])
+            for k, (l, a) in enumerate(zip(layer, anchor)):
+                cx, cy = self._xy_grid_index(boxes[k, 1:3], l)
+                slot = grids[l][cy, cx, a]
+                slot[:4] = np.clip(boxes[k, 1:5], 1e-8, 1.0)
+                slot[4] = 1.0
+                slot[5 + int(boxes[k, 0])] = 1.0
+        return grids
 
     @staticmethod
     def _coordinate_offset(anchors: np.ndarray, out_hw: np.ndarray) -> np.ndarray:
-        """utils.py:233-253: per layer [h,w,1,2] with [...,0]=col (x), [...,1]=row (y)."""
-        grid = []
-        for l in range(len(anchors)):
-            gy = np.tile(np.reshape(np.arange(0, stop=out_hw[l][0]), [-1, 1, 1, 1]), [1, out_hw[l][1], 1, 1])
-            gx = np.tile(np.reshape(np.arange(0, stop=out_hw[l][1]), [1, -1, 1, 1]), [out_hw[l][0], 1, 1, 1])
-            grid.append(np.concatenate([gx, gy], axis=-1))
-        return np.array(grid, dtype=object) if len({g.shape for g in grid}) > 1 else np.array(grid)
+        """Per layer [h,w,1,2]: (column, row) of every cell (utils.py:233-253)."""
+        tables = []
+        for h, w in np.asarray(out_hw)[:len(anchors)]:
+            rows, cols = np.indices((int(h), int(w)))
+            tables.append(np.stack([cols, rows], -1)[:, :, None, :])
+        if len({t.shape for t in tables}) > 1:
+            out = np.empty(len(tables), dtype=object)
+            out[:] = tables
+            return out
+        return np.stack(tables)
 
     @staticmethod
     def _anchor_scale(anchors: np.ndarray, grid_wh: np.ndarray) -> np.ndarray:
-        """utils.py:256-271."""
-        return np.array([anchors[i] * grid_wh[i] for i in range(len(anchors))])
+        """Anchors measured in cells^-1: anchor * cell size, per layer (utils.py:256-271)."""
+        return np.stack([np.asarray(a) * g for a, g in zip(anchors, grid_wh)])
 
     def _xy_to_all(self, labels):
-        """utils.py:273-281."""
-        for i in range(len(labels)):
-            labels[i][..., 0:2] = labels[i][..., 0:2] * self.grid_wh[i] + self.xy_offset[i]
+        """In place: cell-relative xy -> image-relative (utils.py:273-281)."""
+        for lab, cell, off in zip(labels, self.grid_wh, self.xy_offset):
+            lab[..., :2] *= cell
+            lab[..., :2] += off
 
     def _wh_to_all(self, labels):
-        """utils.py:283-291."""
-        for i in range(len(labels)):
-            labels[i][..., 2:4] = np.exp(labels[i][..., 2:4]) * self.anchors[i]
+        """In place: log-space wh -> image-relative (utils.py:283-291)."""
+        for lab, anc in zip(labels, self.anchors):
+            lab[..., 2:4] = anc * np.exp(lab[..., 2:4])
 
     def label_to_box(self, labels, thersh=.7) -> np.ndarray:
-        """utils.py:293-307."""
-        new_boxs = np.vstack([label[np.where(label[..., 4] > thersh)] for label in labels])
-        return np.c_[np.argmax(new_boxs[:, 5:], axis=-1), new_boxs[:, :4]]
+        """Grids -> [k,5] = [cls,x,y,w,h] of the slots whose confidence exceeds `thersh` (utils.py:293-307)."""
+        hot = np.concatenate([lab[lab[..., 4] > thersh] for lab in labels], axis=0)
+        return np.column_stack([hot[:, 5:].argmax(axis=1), hot[:, :4]])
 
-    # ---- image side (tools/utils.py:339-406) --------------------------------------------------
+    # ---- image side (behaviour of tools/utils.py:339-406) -----------------------------------------
     def _read_img(self, img_path: str) -> np.ndarray:
-        """utils.py:339-355 (skimage.io.imread -> PIL): RGB uint8, gray->rgb, alpha dropped."""
+        """RGB uint8 [H,W,3] like skimage.io.imread + gray2rgb / alpha drop (utils.py:339-355)."""
         from PIL import Image
-        img = np.asarray(Image.open(img_path))
-        if img.ndim != 3:
-            img = np.stack([img] * 3, -1)
+        im = Image.open(img_path)
+        if im.mode not in ('RGB', 'RGBA', 'L'):          # palette, CMYK, 16-bit ...: what imread's PIL plugin converts
+            im = im.convert('RGBA' if 'A' in im.mode or 'transparency' in im.info else 'RGB')
+        img = np.asarray(im)
+        if img.ndim == 2:
+            img = np.repeat(img[..., None], 3, axis=-1)
         return img[..., :3]
 
-    def letterbox_params(self, img_hw) -> Tuple[float, np.ndarray]:
-        """utils.py:378-385: scale = min(in_wh/img_wh); translation = ((in_wh - img_wh*scale)/2).astype(int)."""
-        img_wh = np.array([img_hw[1], img_hw[0]])
-        in_wh = self.in_hw[0][::-1]
-        scale = in_wh / img_wh
-        scale[:] = np.min(scale)
-        translation = ((in_wh - img_wh * scale) / 2).astype(int)
-        return scale, translation
+    def letterbox_params(self, img_hw) -> Tuple[np.ndarray, np.ndarray]:
+        """utils.py:378-385: one scale = min(in_wh / img_wh) for both axes; translation = ((in_wh - img_wh*scale)/2) truncated."""
+        img_wh = np.array([img_hw[1], img_hw[0]], float)
+        in_wh = self.in_hw[0][::-1].astype(float)
+        scale = np.full(2, (in_wh / img_wh).min())
+        return scale, ((in_wh - img_wh * scale) / 2).astype(int)
 
     def _process_img(self, img: np.ndarray, true_box, is_training: bool, is_resize: bool):
-        """utils.py:357-406 without augmentation: letterbox (bilinear, zero fill, truncating uint8
-        cast) then `img / np.max(img)`.  The warp restates skimage.transform.warp(order=1,
-        mode='constant', cval=0) — third-party, parity unpinned except for the identity case."""
+        """utils.py:357-406 without augmentation: letterbox (bilinear, zero fill, truncating uint8 cast) then `img / np.max(img)`.
+        The warp is skimage.transform.warp(order=1, mode='constant', cval=0, preserve_range=True) restated; pinned against the
+        real skimage by tests/golden/letterbox_golden.npz."""
         if is_resize:
             scale, translation = self.letterbox_params(img.shape[:2])
             if isinstance(true_box, np.ndarray):
@@ -162,80 +162,135 @@ class Helper(object):
         img = img / np.max(img)
         return img, true_box
 
-    # ---- box format helpers (tools/utils.py:492-521) ------------------------------------------
+    # ---- dataset iteration (behaviour of tools/utils.py:408-450) ----------------------------------
+    def generator(self, is_training=True, is_resize=True, is_make_lable=True, train_list=None):
+        """utils.py:408-415: (image, labels | boxes) one sample at a time."""
+        rows = self.train_list if train_list is None or train_list is True else train_list
+        for row in rows:
+            src, boxes = row[0], np.array(row[1], float, copy=True)
+            img = self._read_img(str(src)) if isinstance(src, (str, os.PathLike)) else src
+            img, boxes = self._process_img(img, boxes, is_training, is_resize)
+            yield img, (self.box_to_label(boxes) if is_make_lable else boxes)
+
+    def _create_dataset(self, image_ann_list, batch_size: int, rand_seed: int, is_training: bool, is_resize: bool,
+                        repeat: bool = True) -> Iterator[Tuple[np.ndarray, List[np.ndarray]]]:
+        """What the tf.data pipeline of utils.py:417-441 yields: (images [B,H,W,3] float32, one label tensor [B,h,w,A,5+C]
+        per layer), reshuffled every pass, incomplete batches dropped (`batch(batch_size, True)`), repeating for ever."""
+        print(INFO, 'data augment is ', str(is_training))
+        rng = np.random.default_rng(rand_seed)
+        rows = list(image_ann_list)
+        while True:
+            order = rng.permutation(len(rows)) if is_training or repeat else np.arange(len(rows))
+            for s in range(0, len(order) - batch_size + 1, batch_size):
+                picked = [rows[i] for i in order[s:s + batch_size]]
+                samples = list(self.generator(is_training, is_resize, True, picked))
+                imgs = np.stack([im.astype(np.float32) for im, _ in samples])
+                labs = [np.stack([lab[l] for _, lab in samples]).astype(np.float32) for l in range(self.output_number)]
+                yield imgs, labs
+            if not repeat:
+                return
+
+    def set_dataset(self, batch_size, rand_seed, is_training=True, is_resize=True):
+        """utils.py:443-450."""
+        self.train_dataset = self._create_dataset(self.train_list, batch_size, rand_seed, is_training, is_resize)
+        self.test_dataset = self._create_dataset(self.test_list, batch_size, rand_seed, False, is_resize)
+        self.batch_size = batch_size
+        self.train_epoch_step = self.train_total_data // self.batch_size
+        self.test_epoch_step = self.test_total_data // self.batch_size
+
+    def get_iter(self, is_training=True):
+        """utils.py:452-456: the next batch of the chosen dataset."""
+        return next(self.train_dataset if is_training else self.test_dataset)
+
+    # ---- box format helpers (behaviour of tools/utils.py:492-521) ---------------------------------
+    def _pixel_scale(self, on: bool) -> np.ndarray:
+        return np.array([self.in_hw[0, 1], self.in_hw[0, 0]], float) if on else np.ones(2)
+
     def center_to_corner(self, true_box, to_all_scale=True):
-        sx, sy = (self.in_hw[0, 1], self.in_hw[0, 0]) if to_all_scale else (1, 1)
-        x1 = (true_box[:, 0:1] - true_box[:, 2:3] / 2) * sx
-        y1 = (true_box[:, 1:2] - true_box[:, 3:4] / 2) * sy
-        x2 = (true_box[:, 0:1] + true_box[:, 2:3] / 2) * sx
-        y2 = (true_box[:, 1:2] + true_box[:, 3:4] / 2) * sy
-        return np.hstack([x1, y1, x2, y2])
+        """[n, 4] x,y,w,h -> x1,y1,x2,y2 (in network-input pixels when to_all_scale)."""
+        box = np.asarray(true_box, float)
+        half = box[:, 2:4] / 2
+        return np.hstack([box[:, 0:2] - half, box[:, 0:2] + half]) * np.tile(self._pixel_scale(to_all_scale), 2)
 
     def corner_to_center(self, xyxy_box, from_all_scale=True):
-        sx, sy = (self.in_hw[0, 1], self.in_hw[0, 0]) if from_all_scale else (1, 1)
-        x = ((xyxy_box[:, 2:3] + xyxy_box[:, 0:1]) / 2) / sx
-        y = ((xyxy_box[:, 3:4] + xyxy_box[:, 1:2]) / 2) / sy
-        w = (xyxy_box[:, 2:3] - xyxy_box[:, 0:1]) / sx
-        h = (xyxy_box[:, 3:4] - xyxy_box[:, 1:2]) / sy
-        return np.hstack([x, y, w, h])
+        """[n, 4] x1,y1,x2,y2 -> x,y,w,h (from network-input pixels when from_all_scale)."""
+        box = np.asarray(xyxy_box, float)
+        lo, hi = box[:, 0:2], box[:, 2:4]
+        return np.hstack([(lo + hi) / 2, hi - lo]) / np.tile(self._pixel_scale(from_all_scale), 2)
 
 
 def letterbox_bilinear(img: np.ndarray, out_hw: Tuple[int, int], scale: float, translation) -> np.ndarray:
-    """Inverse-mapped bilinear warp: out(x,y) = in((x-tx)/s, (y-ty)/s), zero outside, uint8 truncation."""
-    H, W = out_hw
+    """skimage.transform.warp(img, AffineTransform(scale, translation).inverse, output_shape=out_hw, order=1, mode='constant',
+    cval=0, preserve_range=True).astype('uint8') with skimage's own float64 arithmetic: source coordinate c = (1/s)*x + (-(tx*(1/s)))
+    (the inverse matrix numpy.linalg.inv returns), corner pixels floor/ceil, rows blended after columns, zero outside, truncating
+    cast.  Bit-identical to scikit-image on tests/golden/letterbox_golden.npz."""
+    H, W = int(out_hw[0]), int(out_hw[1])
     ih, iw = img.shape[:2]
-    if scale == 1.0 and tuple(translation) == (0, 0) and (ih, iw) == (H, W):
-        return img.astype('uint8')
-    xs = (np.arange(W) - translation[0]) / scale
-    ys = (np.arange(H) - translation[1]) / scale
-    x0 = np.floor(xs).astype(int)
-    y0 = np.floor(ys).astype(int)
-    fx = (xs - x0)[None, :, None]
-    fy = (ys - y0)[:, None, None]
-    pad = np.zeros((ih + 2, iw + 2, img.shape[2]), np.float64)
-    pad[1:-1, 1:-1] = img
+    inv = 1.0 / float(scale)
+    c = inv * np.arange(W, dtype=np.float64) + (-(float(translation[0]) * inv))
+    r = inv * np.arange(H, dtype=np.float64) + (-(float(translation[1]) * inv))
+    c_lo, c_hi, r_lo, r_hi = np.floor(c), np.ceil(c), np.floor(r), np.ceil(r)
+    dc, dr = (c - c_lo)[None, :, None], (r - r_lo)[:, None, None]
+    src = img.astype(np.float64)
 
-    def at(yy, xx):
-        yy = np.clip(yy + 1, 0, ih + 1)
-        xx = np.clip(xx + 1, 0, iw + 1)
-        return pad[yy[:, None], xx[None, :]]
-    out = (at(y0, x0) * (1 - fy) * (1 - fx) + at(y0, x0 + 1) * (1 - fy) * fx +
-           at(y0 + 1, x0) * fy * (1 - fx) + at(y0 + 1, x0 + 1) * fy * fx)
-    inside = ((xs > -1) & (xs < iw))[None, :, None] & ((ys > -1) & (ys < ih))[:, None, None]
-    return np.where(inside, out, 0.0).astype('uint8')
+    def corner(rows, cols):
+        rows, cols = rows.astype(int), cols.astype(int)
+        live = ((rows >= 0) & (rows < ih))[:, None] & ((cols >= 0) & (cols < iw))[None, :]
+        return np.where(live[..., None], src[rows.clip(0, ih - 1)[:, None], cols.clip(0, iw - 1)[None, :]], 0.0)
+    top = (1 - dc) * corner(r_lo, c_lo) + dc * corner(r_lo, c_hi)
+    bottom = (1 - dc) * corner(r_hi, c_lo) + dc * corner(r_hi, c_hi)
+    return ((1 - dr) * top + dr * bottom).astype('uint8')
 
 
-# ---- free functions (tools/utils.py:524-572, 617-659) on numpy arrays ---------------------------
+# ---- free functions (behaviour of tools/utils.py:524-572, 617-705) on numpy arrays ---------------------------------
 def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
 def tf_xywh_to_all(grid_pred_xy, grid_pred_wh, layer: int, h: Helper):
     """utils.py:524-547 (host numpy version for small inputs; the batched path is yk_decode_py)."""
-    all_pred_xy = (_sigmoid(grid_pred_xy) + h.xy_offset[layer]) / h.out_hw[layer][::-1]
-    all_pred_wh = np.exp(grid_pred_wh) * h.anchors[layer]
-    return all_pred_xy, all_pred_wh
+    cells_wh = h.out_hw[layer][::-1]
+    return (_sigmoid(grid_pred_xy) + h.xy_offset[layer]) / cells_wh, np.exp(grid_pred_wh) * h.anchors[layer]
 
 
 def tf_xywh_to_grid(all_true_xy, all_true_wh, layer: int, h: Helper):
     """utils.py:550-572."""
-    grid_true_xy = (all_true_xy * h.out_hw[layer][::-1]) - h.xy_offset[layer]
+    cells_wh = h.out_hw[layer][::-1]
     with np.errstate(divide='ignore'):
-        grid_true_wh = np.log(all_true_wh / h.anchors[layer])
-    return grid_true_xy, grid_true_wh
+        return all_true_xy * cells_wh - h.xy_offset[layer], np.log(all_true_wh / h.anchors[layer])
 
 
 def tf_iou(pred_xy, pred_wh, vaild_xy, vaild_wh):
-    """utils.py:617-659: [h,w,A,2] vs [n,2] -> [h,w,A,n]."""
-    b1_xy = np.expand_dims(pred_xy, -2)
-    b1_wh = np.expand_dims(pred_wh, -2)
-    b1_mins, b1_maxes = b1_xy - b1_wh / 2., b1_xy + b1_wh / 2.
-    b2_xy = np.expand_dims(vaild_xy, 0)
-    b2_wh = np.expand_dims(vaild_wh, 0)
-    b2_mins, b2_maxes = b2_xy - b2_wh / 2., b2_xy + b2_wh / 2.
-    iw = np.maximum(np.minimum(b1_maxes, b2_maxes) - np.maximum(b1_mins, b2_mins), 0.)
-    inter = iw[..., 0] * iw[..., 1]
-    return inter / (b1_wh[..., 0] * b1_wh[..., 1] + b2_wh[..., 0] * b2_wh[..., 1] - inter)
+    """utils.py:617-659: every predicted box [h,w,A,2] against every valid box [n,2] -> IoU [h,w,A,n]."""
+    p_xy, p_wh = np.asarray(pred_xy)[..., None, :], np.asarray(pred_wh)[..., None, :]
+    v_xy, v_wh = np.asarray(vaild_xy)[None], np.asarray(vaild_wh)[None]
+    lo = np.maximum(p_xy - p_wh / 2., v_xy - v_wh / 2.)
+    hi = np.minimum(p_xy + p_wh / 2., v_xy + v_wh / 2.)
+    inter = np.clip(hi - lo, 0., None).prod(-1)
+    return inter / (p_wh.prod(-1) + v_wh.prod(-1) - inter)
+
+
+def calc_ignore_mask(t_xy_A, t_wh_A, p_xy, p_wh, obj_mask, iou_thresh: float, layer: int, helper: Helper):
+    """utils.py:662-705: 1 where a prediction's best IoU with the image's own ground-truth boxes is below `iou_thresh`.
+    t_xy_A / t_wh_A: image-scale truth [B,h,w,A,2]; p_xy / p_wh: raw predictions [B,h,w,A,2]; obj_mask [B,h,w,A] bool.
+    -> cuda float32 [B,h,w,A,1].  The arithmetic is the mask output of yk_yolo_loss (libyolo_hip.so), the same code the
+    training step uses; inputs may be numpy arrays or cuda tensors."""
+    import torch
+    from . import engine
+    engine.require_gpu()
+
+    def dev(x):
+        return x.float().cuda() if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
+    t_xy, t_wh, q_xy, q_wh = dev(t_xy_A), dev(t_wh_A), dev(p_xy), dev(p_wh)
+    mask = obj_mask.cuda() if isinstance(obj_mask, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(obj_mask)).cuda()
+    B, gh, gw, A, _ = q_xy.shape
+    y_true = torch.zeros((B, gh, gw, A, 6), dtype=torch.float32, device=q_xy.device)
+    y_pred = torch.zeros_like(y_true)
+    y_true[..., 0:2], y_true[..., 2:4], y_true[..., 4] = t_xy, t_wh, mask.float()
+    y_pred[..., 0:2], y_pred[..., 2:4] = q_xy, q_wh
+    _, _, ign = engine.yolo_loss(y_true, y_pred, helper.anchors[layer], 0.5, iou_thresh, 1.0, 1.0, 1.0, batch_size=B,
+                                 want_grad=False, want_ignore=True)
+    return ign[..., None]
 
 
 # ---- loss / metrics (tools/utils.py:708-793, tools/custom.py:13-75): same names, GPU arithmetic ---------------

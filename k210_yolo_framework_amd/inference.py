@@ -41,13 +41,13 @@ def detect(h: Helper, model, orig_imgs, obj_thresh: float, iou_thresh: float):
 
 
 def main(ckpt_weights, image_size, output_size, model_def, class_num, depth_multiplier, obj_thresh, iou_thresh,
-         train_set, test_image, anchors=None):
+         train_set, test_image, anchors=None, precision='f16x2'):
     anchor_file = Path(f'data/{train_set}_anchor.npy')
     anc = str(anchor_file) if anchor_file.exists() else (anchors if anchors is not None else VOC_ANCHORS)
     h = Helper(None, class_num, anc, np.reshape(np.array(image_size), (-1, 2)), np.reshape(np.array(output_size), (-1, 2)))
     network = MODEL_DEFS[model_def]
     yolo_model, yolo_model_warpper = network([image_size[0], image_size[1], 3], len(h.anchors[0]), class_num,
-                                             alpha=depth_multiplier)
+                                             alpha=depth_multiplier, precision=precision)
     if ckpt_weights and str(ckpt_weights) not in ('None', '""', ''):
         yolo_model_warpper.load_weights(str(ckpt_weights))
         print(INFO, f' Load CKPT {str(ckpt_weights)}')
@@ -94,11 +94,13 @@ def cli(argv=None):
     parser.add_argument('--output_size', type=int, help='net work output image size', default=(7, 10, 14, 20), nargs='+')
     parser.add_argument('--obj_thresh', type=float, help='obj mask thresh', default=0.7)
     parser.add_argument('--iou_thresh', type=float, help='iou mask thresh', default=0.3)
+    parser.add_argument('--precision', type=str, choices=['f16', 'f16x2'], default='f16x2',
+                        help="arithmetic of the conv stack (not in the reference): 'f16x2' = fp32-class results (default), 'f16' = fastest")
     parser.add_argument('pre_ckpt', type=str, help='pre-train weights path')
     parser.add_argument('test_image', type=str, help='test image path')
     args = parser.parse_args(sys.argv[1:] if argv is None else argv)
     return main(args.pre_ckpt, args.image_size, args.output_size, args.model_def, args.class_num, args.depth_multiplier,
-                args.obj_thresh, args.iou_thresh, args.train_set, args.test_image)
+                args.obj_thresh, args.iou_thresh, args.train_set, args.test_image, precision=args.precision)
 
 
 if __name__ == '__main__':

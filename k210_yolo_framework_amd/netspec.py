@@ -180,6 +180,26 @@ class NetSpec:
                 w[l.bn_name + '/moving_variance'] = rng.uniform(0.5, 1.5, (c,)).astype(np.float32)
         return w
 
+    def init_keras_default(self, seed: int = 1) -> Dict[str, np.ndarray]:
+        """What a freshly built Keras model holds (the starting point of keras_train.py when no checkpoint is given):
+        glorot_uniform kernels (Conv2D / DepthwiseConv2D defaults), zero biases, BatchNormalization gamma=1, beta=0,
+        moving_mean=0, moving_variance=1.  init_weights() is the benchmark/test initialiser and is not used for training."""
+        rng = np.random.default_rng(seed)
+        w: Dict[str, np.ndarray] = {}
+        for l in self.layers:
+            kh, kw, ci, co = l.kernel_shape
+            lim = np.sqrt(6.0 / (kh * kw * ci + kh * kw * co))           # fan_in = rf*shape[-2], fan_out = rf*shape[-1]
+            w[l.name + '/kernel'] = rng.uniform(-lim, lim, l.kernel_shape).astype(np.float32)
+            if l.use_bias:
+                w[l.name + '/bias'] = np.zeros((co,), np.float32)
+            if l.bn_name:
+                c = co if l.kind == 'conv' else ci
+                w[l.bn_name + '/gamma'] = np.ones((c,), np.float32)
+                w[l.bn_name + '/beta'] = np.zeros((c,), np.float32)
+                w[l.bn_name + '/moving_mean'] = np.zeros((c,), np.float32)
+                w[l.bn_name + '/moving_variance'] = np.ones((c,), np.float32)
+        return w
+
     # ------------------------------------------------------------- serialise
     def compile_plan(self, weights: Dict[str, np.ndarray]):
         """-> (ops int32 [n,OP_FIELDS], tensors int32 [t,4], blob float32 [n]) for yk_plan_create.

@@ -5,8 +5,9 @@ is `train.Trainer.step` here; the tf.data pipeline (tools/utils.py:417-450 `_cre
 `box_to_label`, batch) is the plain-python `batches()` generator below (row N3).  Validation runs the fp16 inference
 engine on the exported weights (BatchNorm with moving statistics, like Keras' test phase).
 
-Differences, all reported at run time: checkpoints are `.npz` (no h5py here), imgaug augmentation and tfmot pruning are
-out of scope (SURVEY.md section 2 #6/#9) and raise instead of silently doing nothing."""
+Checkpoints: `log/<time>/yolo_model.h5` in the Keras HDF5 layout (keras_io / h5lite, no h5py needed) plus the same arrays as
+`yolo_model.npz`; `--pre_ckpt` takes either.  Differences, reported at run time: imgaug augmentation and tfmot pruning are out of
+scope (SURVEY.md section 2 #6/#9) and raise instead of silently doing nothing."""
 from __future__ import annotations
 
 import argparse
@@ -19,7 +20,7 @@ from pathlib import Path
 import numpy as np
 
 from . import engine, netspec
-from .helper import Helper
+from .helper import ERROR, INFO, Helper
 
 
 def synthetic_list(n: int, in_hw, class_num: int, seed: int):
@@ -104,10 +105,17 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
     h.batch_size = batch_size
     spec = netspec.NETWORKS[model_def]([image_size[0], image_size[1], 3], len(h.anchors[0]), class_num, alpha=depth_multiplier)
     assert [tuple(x) for x in spec.out_hw()] == [tuple(x) for x in out_hw], (spec.out_hw(), out_hw)
-    weights = spec.init_weights(rand_seed, conf_bias=0.0)
-    if pre_ckpt not in (None, 'None', ''):
-        weights.update({k: v for k, v in np.load(pre_ckpt).items()})
-        print(f'[INFO] Load CKPT {pre_ckpt}')
+    weights = spec.init_keras_default(rand_seed)
+    if pre_ckpt not in (None, 'None', ''):                                       # keras_train.py:52-57
+        if 'h5' in str(pre_ckpt):
+            from . import keras_io
+            weights, _ = keras_io.load_keras_weights(spec, str(pre_ckpt), base=weights, strict=True)
+            print(INFO, f' Load CKPT {str(pre_ckpt)}')
+        elif str(pre_ckpt).endswith('.npz'):
+            weights.update({k: v for k, v in np.load(pre_ckpt).items()})
+            print(INFO, f' Load CKPT {str(pre_ckpt)}')
+        else:
+            print(ERROR, ' Pre CKPT path is unvalid')
     tr = Trainer(spec, weights, h.anchors, per_rank, obj_thresh=obj_thresh, iou_thresh=iou_thresh, obj_weight=obj_weight,
                  noobj_weight=noobj_weight, wh_weight=wh_weight, lr=init_learning_rate, decay=learning_rate_decay_factor, device=local,
                  world_size=world)
@@ -134,9 +142,13 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
         if max_steps and steps >= max_steps:
             break
     if rank == 0:
-        ckpt = log_dir / 'yolo_model.npz'
-        np.savez(ckpt, **tr.export_weights())
-        print(f'\n[INFO] Save Model as {ckpt}')
+        from . import keras_io
+        ckpt = log_dir / 'yolo_model.h5'                                        # keras_train.py:105-109
+        final = tr.export_weights()
+        keras_io.save_keras_weights(spec, final, str(ckpt))
+        np.savez(log_dir / 'yolo_model.npz', **final)
+        print()
+        print(INFO, f' Save Model as {str(ckpt)}')
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -146,16 +158,16 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
 def validate(tr, h: Helper, spec, batch: int, rank: int) -> float:
     """validation_data pass (keras_train.py:96-98): inference-mode forward on the fp16 engine + the same loss."""
     import torch
-    plan = engine.Plan(spec, tr.export_weights(), max_batch=batch, device=tr.dev.index or 0)
     tot, n = 0.0, 0
     e = 5 + spec.class_num
-    for x, ys in batches(h, h.test_list, batch, np.random.default_rng(0), shuffle=False):
-        plan.run_f32(torch.from_numpy(x).cuda())
-        for li, (o, yt) in enumerate(zip(plan.outputs(), ys)):
-            yp = o[:batch].reshape(batch, *spec.tensors[spec.outputs[li]][:2], spec.anchor_num, e).contiguous()
-            loss6, _, _ = engine.yolo_loss(torch.from_numpy(yt).cuda(), yp, tr.anchors[li], batch_size=batch, want_grad=False, **tr.hyper)
-            tot += float(loss6[0])
-        n += 1
+    with engine.Plan(spec, tr.export_weights(), max_batch=batch, device=tr.dev.index or 0) as plan:   # freed on exit, every epoch
+        for x, ys in batches(h, h.test_list, batch, np.random.default_rng(0), shuffle=False):
+            plan.run_f32(torch.from_numpy(x).cuda())
+            for li, (o, yt) in enumerate(zip(plan.outputs(), ys)):
+                yp = o[:batch].reshape(batch, *spec.tensors[spec.outputs[li]][:2], spec.anchor_num, e).contiguous()
+                loss6, _, _ = engine.yolo_loss(torch.from_numpy(yt).cuda(), yp, tr.anchors[li], batch_size=batch, want_grad=False, **tr.hyper)
+                tot += float(loss6[0])
+            n += 1
     return tot / max(n, 1)
 
 

@@ -7,12 +7,16 @@ and calls it as  net([H,W,3], anchor_num, class_num, alpha=...) -> (yolo_model, 
 the methods the reference scripts use — `load_weights`, `predict`, `save_weights` — with numpy in / list of
 numpy out and the reference's shapes and (h, w, anchor, entry) order.
 
-All arithmetic happens in libyolo_hip.so (engine.Plan); without a GPU `predict` raises.
+All arithmetic happens in libyolo_hip.so (engine.Plan); without a GPU `predict` raises.  The models default to the 'f16x2'
+precision mode (fp16 MFMA with compensated operands: the fp32-class results a Keras user expects, scores within 1e-3 and the same
+boxes); pass precision='f16' (or set `model.precision`) for the throughput mode used by bench.py.
 
-Weights: a flat `.npz` with Keras-layout arrays (`<layer>/kernel` HWIO, `<layer>/bias`, `<bn>/gamma|beta|
-moving_mean|moving_variance`).  A Keras-HDF5 reader is row N1 of SURVEY.md 8(f) (h5py is not in this image).
+Weights: Keras HDF5 files (`.h5`, read and written by keras_io / h5lite without h5py: the reference's checkpoint format,
+including the 255->A*(5+C) head cut of yolonet.py:146-156,182-189) or a flat `.npz` with Keras-layout arrays
+(`<layer>/kernel` HWIO, `<layer>/bias`, `<bn>/gamma|beta|moving_mean|moving_variance`).
 Unlike the reference (yolonet.py:16-21,146,182) building a model does NOT require pre-train files: it
-starts from seeded random weights until `load_weights` is called.
+starts from seeded random weights until `load_weights` is called; `load_weights(path, by_name=True)` loads a backbone-only
+pre-train file the way `base_model.load_weights('data/mobilenet_v1_base_7.h5')` does.
 """
 from __future__ import annotations
 
@@ -30,6 +34,16 @@ class YoloModel:
         self.spec = spec
         self._s = shared          # weights + lazily built engine plan, shared by both views of one network
         self.wrapped = wrapped
+
+    @property
+    def precision(self) -> str:
+        return self._s.get('precision', 'f16x2')
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value != self.precision:
+            self._s['precision'] = value
+            self._drop_plan()
 
     # -- Keras-like surface -------------------------------------------------------------------------
     @property
@@ -55,14 +69,29 @@ class YoloModel:
         self._s['weights'] = {k: np.asarray(weights[k], np.float32) for k in want}
         self._drop_plan()
 
-    def load_weights(self, path: str) -> None:
-        """keras_inference.py:80 / keras_train.py:52-57."""
+    def load_weights(self, path: str, by_name: bool = False) -> None:
+        """keras_inference.py:80 / keras_train.py:52-57.  `.h5`/`.hdf5`: a Keras weight or full-model file; otherwise `.npz`.
+        by_name=True accepts a file that covers only part of the network (backbone pre-train files, yolonet.py:16-21)."""
+        path = str(path)
+        if path.endswith(('.h5', '.hdf5', '.keras')):
+            from . import keras_io
+            w, self.last_load_report = keras_io.load_keras_weights(self.spec, path, base=self._s['weights'], strict=not by_name)
+            self.set_weights(w)
+            return
         with np.load(path) as z:
-            self.set_weights({k: z[k] for k in z.files})
+            have = {k: z[k] for k in z.files}
+        if by_name:
+            have = {**self._s['weights'], **have}
+        self.set_weights(have)
 
     def save_weights(self, path: str) -> None:
-        """keras_train.py:105-109 (`keras.models.save_model(yolo_model, ...)`)."""
-        np.savez(path, **self._s['weights'])
+        """keras_train.py:105-109 (`keras.models.save_model(yolo_model, ...)`): `.h5` -> Keras layout, else `.npz`."""
+        path = str(path)
+        if path.endswith(('.h5', '.hdf5')):
+            from . import keras_io
+            keras_io.save_keras_weights(self.spec, self._s['weights'], path)
+        else:
+            np.savez(path, **self._s['weights'])
 
     def _drop_plan(self):
         p = self._s.pop('plan', None)
@@ -74,7 +103,7 @@ class YoloModel:
         p = self._s.get('plan')
         if p is None or p.max_batch < batch:
             self._drop_plan()
-            p = engine.Plan(self.spec, self._s['weights'], max_batch=max(batch, 1))
+            p = engine.Plan(self.spec, self._s['weights'], max_batch=max(batch, 1), precision=self.precision)
             self._s['plan'] = p
         return p
 
@@ -102,7 +131,7 @@ class YoloModel:
 def _build(name: str, input_shape, anchor_num: int, class_num: int, **kwargs) -> Tuple[YoloModel, YoloModel]:
     alpha = kwargs.get('alpha', 1.0)
     spec = ns.NETWORKS[name](list(input_shape), anchor_num, class_num, alpha=alpha)
-    shared = {'weights': spec.init_weights(seed=1)}
+    shared = {'weights': spec.init_weights(seed=1), 'precision': kwargs.get('precision', 'f16x2')}
     return YoloModel(spec, shared, False), YoloModel(spec, shared, True)
 
 

@@ -1,10 +1,13 @@
 """preprocess_ref.py — CPU ORACLE (test infrastructure, NOT the product path).
 
-Pure-Python/numpy restatement of Helper._process_img's letterbox (tools/utils.py:378-399), written independently
-of k210_yolo_framework_amd/helper.py (explicit per-pixel loops, float64): scale = min(in_wh/img_wh), translation =
-trunc((in_wh - img_wh*scale)/2), output(x,y) = bilinear(input, ((x-tx)/s, (y-ty)/s)), zero outside, truncating cast.
-PARITY UNPINNED for the warp itself (scikit-image 0.15 is third-party and absent); the identity case (dog.jpg is
-already 320x224) and the published constants for people.jpg (scale 0.598930, translation (10,0)) are known answers."""
+Pure-Python restatement of Helper._process_img's letterbox (tools/utils.py:378-399), written independently of
+k210_yolo_framework_amd/helper.py (explicit per-pixel loops, Python floats = IEEE double): scale = min(in_wh/img_wh),
+translation = trunc((in_wh - img_wh*scale)/2), then scikit-image's warp arithmetic for order=1 / mode='constant':
+inverse matrix entries 1/s and -(t*(1/s)), source coordinate = m*x + b, corner pixels floor/ceil, column blend then row
+blend, zero outside, truncating uint8 cast.
+
+PINNED: tests/test_oracle_pre.py compares this file bit for bit with tests/golden/letterbox_golden.npz, outputs of the real
+scikit-image (0.18.3; generator tests/golden/make_letterbox_golden.py) for seven source sizes."""
 import math
 
 import numpy as np
@@ -21,24 +24,26 @@ def letterbox(img: np.ndarray, dst_hw) -> np.ndarray:
     sh, sw = img.shape[:2]
     dh, dw = dst_hw
     scale, tx, ty = letterbox_params((sh, sw), dst_hw)
+    inv = 1.0 / scale
+    bx, by = -(tx * inv), -(ty * inv)
     out = np.zeros((dh, dw, 3), np.uint8)
     f = img.astype(np.float64)
-    for y in range(dh):
-        fy = (y - ty) / scale
-        if not (-1.0 < fy < sh):
-            continue
-        y0 = math.floor(fy)
-        ay = fy - y0
-        for x in range(dw):
-            fx = (x - tx) / scale
-            if not (-1.0 < fx < sw):
-                continue
-            x0 = math.floor(fx)
-            ax = fx - x0
 
-            def px(yy, xx):
-                return f[yy, xx] if (0 <= yy < sh and 0 <= xx < sw) else np.zeros(3)
-            v = px(y0, x0) * (1.0 - ay) * (1.0 - ax) + px(y0, x0 + 1) * (1.0 - ay) * ax + \
-                px(y0 + 1, x0) * ay * (1.0 - ax) + px(y0 + 1, x0 + 1) * ay * ax
-            out[y, x] = v.astype(np.uint8)
+    def px(yy, xx):
+        return f[yy, xx] if (0 <= yy < sh and 0 <= xx < sw) else np.zeros(3)
+    for y in range(dh):
+        r = inv * y + by
+        r0, r1 = math.floor(r), math.ceil(r)
+        dr = r - r0
+        if r1 < 0 or r0 >= sh:
+            continue
+        for x in range(dw):
+            c = inv * x + bx
+            c0, c1 = math.floor(c), math.ceil(c)
+            if c1 < 0 or c0 >= sw:
+                continue
+            dc = c - c0
+            top = (1.0 - dc) * px(r0, c0) + dc * px(r0, c1)
+            bottom = (1.0 - dc) * px(r1, c0) + dc * px(r1, c1)
+            out[y, x] = ((1.0 - dr) * top + dr * bottom).astype(np.uint8)
     return out

@@ -1,13 +1,16 @@
 """End to end on the GPU: u8 frames -> conv stack -> Python-mode decode + NMS, vs the CPU oracle chain
 (normalise -> yolo_net_ref fp32 / fp16-emulating -> decode_ref), at BASELINE's headline config and size.
 
-North-star tolerance (BASELINE.json): class / box indices exact, scores and box coords within 1e-3.
-What fp16 activation storage (prescribed by the same north star) delivers on the synthetic SURVEY 8(d)
-weights (logit rms 3.3, |logit| up to 17): score error mean ~2e-4, max ~2e-3 over ~1400 detections;
-so the assertions here are: mean <= 1e-3 (the north-star figure), max <= TOL_MAX = 5e-3, and exact
-class/order once detections whose score lies within MARGIN of the obj threshold are set aside
-(membership there is not decidable at this precision).  Box coords are compared relative to the box
-size (w,h = exp(t)*anchor scales the logit error by the box size itself)."""
+North-star tolerance (BASELINE.json): class / box indices exact, scores and box coords within 1e-3 of the fp32 path.
+  * precision 'f16x2' (fp32 activations, compensated fp16 MFMA operands) is held to exactly that, on all 32 images of K2 with the
+    undamped SURVEY 8(d) weights: the same detections in the same order (class sequence and count per image - NMS survivors
+    are box identities), every score within 1e-3 (measured ~3e-6), every box corner within 1e-3 of the box size.
+  * precision 'f16' (fp16 activation storage, the throughput mode) cannot meet the max bound by construction - 20 layers of
+    2^-11 roundings, error budget in DESIGN.md 4 - and is held to that budget: mean score error <= 1e-3, max <= TOL_MAX_F16,
+    >= 97 % of the detections reproduced away from the threshold margin."""
+import contextlib
+import io
+
 import numpy as np
 import pytest
 
@@ -17,15 +20,16 @@ from k210_yolo_framework_amd import netspec as ns
 from k210_yolo_framework_amd.helper import VOC_ANCHORS
 
 pytestmark = pytest.mark.gpu
-MARGIN = 6e-3
-TOL_MAX = 5e-3
+MARGIN = 6e-3          # f16 mode only: detections this close to the obj threshold are not decidable at fp16 storage precision
+TOL_MAX = 5e-3         # f16 mode only (TOL_MAX_F16): worst-case score drift allowed by the error budget
+NORTH_STAR = 1e-3      # f16x2 mode: BASELINE.json's tolerance, asserted as a MAX over every detection
 
 
-def _gpu(spec, w, frames, obj, iou, image_hw=None):
+def _gpu(spec, w, frames, obj, iou, image_hw=None, precision='f16'):
     import torch
     from k210_yolo_framework_amd import engine
     B = frames.shape[0]
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, precision=precision)
     plan.run_u8(torch.from_numpy(frames).cuda())
     cfg = engine.make_decode_cfg(VOC_ANCHORS, spec.class_num, spec.in_hw, spec.out_hw())
     dets, counts = engine.decode_py(cfg, plan.outputs(), B, image_hw, obj, iou)
@@ -58,6 +62,90 @@ def _match(got, ref_dets, ref_scores_all, obj, hw):
     if es_all:
         assert np.mean(es_all) <= 1e-3, np.mean(es_all)          # the north-star figure holds on average
     return paired, len(r), len(g)
+
+
+def _assert_north_star(dets, ref_dets, tag):
+    """Same detections in the same order; scores within 1e-3; corners within 1e-3 of the box size (w,h = exp(t)*anchor scales
+    the logit error by the box size itself; boxes are in pixels of the original image)."""
+    n = 0
+    for b, (g, r) in enumerate(zip(dets, ref_dets)):
+        assert len(g) == len(r), (tag, b, len(g), len(r))
+        if not len(r):
+            continue
+        assert np.array_equal(g[:, 5], r[:, 5]), (tag, b)                       # class of every detection, class-major order
+        assert np.abs(g[:, 4] - r[:, 4]).max() <= NORTH_STAR, (tag, b, np.abs(g[:, 4] - r[:, 4]).max())
+        size = np.maximum(np.maximum(r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]), 1.0)[:, None]
+        assert (np.abs(g[:, :4] - r[:, :4]) / size).max() <= NORTH_STAR, (tag, b)   # the same box, not a neighbour
+        n += len(r)
+    return n
+
+
+def test_north_star_tolerance_headline_config_all_32_images():
+    """BASELINE configs[1] at full size in the f16x2 mode vs the FP32 oracle: indices exact, scores / coords within 1e-3 (max)."""
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=1)                                               # undamped SURVEY 8(d) initialisation
+    frames = np.random.default_rng(0).integers(0, 256, (32, 224, 320, 3), dtype=np.uint8)
+    outs, dets = _gpu(spec, w, frames, 0.7, 0.5, precision='f16x2')
+    ref32 = oracle.net_forward(spec.compile_plan(w), oracle.normalise_u8(frames), emulate_f16=False, out_ids=spec.outputs)
+    for g, r in zip(outs, ref32):
+        assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max()                    # logits: measured 2e-6 relative
+    rd = dr.decode_batch([r.reshape(32, r.shape[1], r.shape[2], 3, 25) for r in ref32], VOC_ANCHORS, (224, 320), (224, 320), 0.7, 0.5)
+    n = _assert_north_star(dets, [x[0] for x in rd], 'K2 f16x2')
+    assert n > 1000, n                                                          # ~350 detections per image on these weights
+
+
+@pytest.mark.parametrize('name,shape,alpha,B', [('yolo_mobilev2', (224, 320, 3), 1.0, 4), ('tiny_yolo', (416, 416, 3), 1.0, 2)])
+def test_north_star_tolerance_other_networks(name, shape, alpha, B):
+    spec = ns.NETWORKS[name](shape, 3, 20, alpha=alpha)
+    w = spec.init_weights(seed=1)                                               # undamped, also for MobileNet-v2
+    frames = np.random.default_rng(5).integers(0, 256, (B, *shape), dtype=np.uint8)
+    outs, dets = _gpu(spec, w, frames, 0.7, 0.5, precision='f16x2')
+    ref32 = oracle.net_forward(spec.compile_plan(w), oracle.normalise_u8(frames), emulate_f16=False, out_ids=spec.outputs)
+    rd = dr.decode_batch([r.reshape(B, r.shape[1], r.shape[2], 3, 25) for r in ref32], VOC_ANCHORS, shape[:2], shape[:2], 0.7, 0.5)
+    assert _assert_north_star(dets, [x[0] for x in rd], name) > 50
+
+
+def test_make_inference_cli_prints_the_reference_table(tmp_path, capsys):
+    """BASELINE configs[0] (`make inference MODEL=yolo_mobilev1 DEPTHMUL=0.75 CKPT=... IMG=...`): the CLI end to end - Keras .h5
+    checkpoint in, `[top left bottom right score class]` rows out (keras_inference.py:146,154) - against the oracle chain
+    Helper._read_img -> letterbox -> img/max -> fp32 conv stack -> decode_ref on the same file."""
+    from k210_yolo_framework_amd import inference, keras_io
+    from k210_yolo_framework_amd.helper import Helper
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=1)
+    ck = tmp_path / 'yolo_model.h5'
+    keras_io.save_keras_weights(spec, w, ck)
+    img_path = 'data/synthetic_320x224.jpg'
+    argv = [str(ck), img_path, '--model_def', 'yolo_mobilev1', '--depth_multiplier', '0.75', '--obj_thresh', '0.7', '--iou_thresh', '0.5',
+            '--image_size', '224', '320', '--output_size', '7', '10', '14', '20', '--train_set', 'voc', '--class_num', '20']
+    got = inference.cli(argv)
+    out = capsys.readouterr().out
+    assert f'[ INFO  ]  Load CKPT {ck}' in out
+    h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [[7, 10], [14, 20]])
+    orig = h._read_img(img_path)
+    x, _ = h._process_img(orig, None, is_training=False, is_resize=True)
+    ref32 = oracle.net_forward(spec.compile_plan(w), x[None].astype(np.float32), emulate_f16=False, out_ids=spec.outputs)
+    rd = dr.decode_batch([r.reshape(1, r.shape[1], r.shape[2], 3, 25) for r in ref32], VOC_ANCHORS, (224, 320), orig.shape[:2], 0.7, 0.5)[0][0]
+    assert len(rd) > 0 and _assert_north_star([got], [rd], 'cli') == len(rd)
+    lines = [l for l in out.splitlines() if l.startswith('[') and not l.startswith('[ ')]
+    assert lines[0] == '[top\tleft\tbottom\tright\tscore\tclass]'
+    want = [f'[{t:.1f}\t{l:.1f}\t{b:.1f}\t{r:.1f}\t{s:.2f}\t{int(c):2d}]' for t, l, b, r, s, c in rd]
+    assert len(lines) == 1 + len(want)
+    # the printed rows themselves: same format, same class column; a printed digit may differ where the value sits on a rounding
+    # boundary of the one-decimal format (the synthetic weights produce boxes thousands of pixels wide: 1e-3 of the box size > 0.05)
+    for a, b in zip(lines[1:], want):
+        fa, fb = a.strip('[]').split('\t'), b.strip('[]').split('\t')
+        assert len(fa) == 6 and fa[5] == fb[5], (a, b)
+        va, vb = np.array(fa[:5], float), np.array(fb[:5], float)
+        size = max(vb[2] - vb[0], vb[3] - vb[1], 1.0)
+        assert np.abs(va[:4] - vb[:4]).max() <= 0.1 + NORTH_STAR * size and abs(va[4] - vb[4]) <= 0.011, (a, b)
+    same = sum(a == b for a, b in zip(lines[1:], want))
+    assert same >= 0.8 * len(want), (same, len(want))
+    # no detections -> the reference's note (keras_inference.py:176)
+    argv2 = list(argv)
+    argv2[argv2.index('--obj_thresh') + 1] = '0.99999999'
+    assert len(inference.cli(argv2)) == 0
+    assert 'no boxes detected' in capsys.readouterr().out
 
 
 @pytest.mark.parametrize('B', [4, 32])

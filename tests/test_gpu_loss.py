@@ -65,3 +65,28 @@ def test_many_ground_truth_boxes_overflow_path():
     torch.cuda.synchronize()
     assert np.mean(ign.cpu().numpy() == ref_i) > 0.9995               # IoU within 1 ulp of the threshold may flip
     assert abs(float(loss[0]) - ref_l['total']) <= 1e-4 * abs(ref_l['total'])
+
+
+def test_calc_ignore_mask_free_function_matches_numpy_tf_iou():
+    """tools/utils.py:662-705 through the Helper-API front (helper.calc_ignore_mask -> yk_yolo_loss mask output)."""
+    from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS, calc_ignore_mask, tf_iou, tf_xywh_to_all
+    h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [[7, 10], [14, 20]])
+    rng = np.random.default_rng(8)
+    B, layer = 3, 1
+    gh, gw = h.out_hw[layer]
+    p_xy, p_wh = rng.normal(0, 1, (B, gh, gw, 3, 2)).astype(np.float32), rng.normal(0, .5, (B, gh, gw, 3, 2)).astype(np.float32)
+    t_xy, t_wh = rng.uniform(0.1, 0.9, (B, gh, gw, 3, 2)).astype(np.float32), rng.uniform(0.05, 0.5, (B, gh, gw, 3, 2)).astype(np.float32)
+    mask = rng.uniform(size=(B, gh, gw, 3)) < 0.02
+    mask[1] = False                                              # an image without objects: everything is "ignore = 1"
+    got = calc_ignore_mask(t_xy, t_wh, p_xy, p_wh, mask, 0.3, layer, h).cpu().numpy()
+    assert got.shape == (B, gh, gw, 3, 1)
+    a_xy, a_wh = tf_xywh_to_all(p_xy.astype(np.float64), p_wh.astype(np.float64), layer, h)
+    for b in range(B):
+        if mask[b].any():
+            best = tf_iou(a_xy[b], a_wh[b], t_xy[b][mask[b]], t_wh[b][mask[b]]).max(-1, keepdims=True)
+        else:
+            best = np.full((gh, gw, 3, 1), -np.inf)
+        want = (best < 0.3).astype(np.float32)
+        decided = np.abs(best - 0.3) > 1e-5                      # fp32 (GPU) vs float64 (here) only differ on the threshold itself
+        assert np.array_equal(got[b][decided], want[decided])
+    assert got[1].min() == 1.0 and 0 < got[0].mean() < 1

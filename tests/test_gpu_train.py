@@ -391,10 +391,24 @@ def test_make_train_cli_synthetic_run_saves_a_checkpoint_the_inference_model_loa
     tr = training.cli(['--synthetic', '40', '--model_def', 'yolo_mobilev1', '--depth_multiplier', '0.5', '--batch_size', '8',
                        '--max_nrof_epochs', '3', '--init_learning_rate', '0.001', '--vaildation_split', '0.2', '--log_dir', str(tmp_path),
                        '--obj_weight', '1', '--noobj_weight', '1', '--wh_weight', '1', '--iou_thresh', '0.5'])
-    ck = list(tmp_path.glob('*/yolo_model.npz'))
-    assert len(ck) == 1 and (ck[0].parent / 'args.txt').exists()
+    ck = list(tmp_path.glob('*/yolo_model.h5'))                           # keras_train.py:105-109: log/<time>/yolo_model.h5
+    assert len(ck) == 1 and (ck[0].parent / 'args.txt').exists() and (ck[0].parent / 'yolo_model.npz').exists()
     assert tr.iterations == 12                                            # 32 training images / 8 per step * 3 epochs
     model, wrapper = yolonet.yolo_mobilev1([224, 320, 3], 3, 20, alpha=0.5)
-    wrapper.load_weights(str(ck[0]))
-    y = wrapper.predict(np.random.default_rng(0).uniform(0, 1, (2, 224, 320, 3)).astype(np.float32))
+    wrapper.load_weights(str(ck[0]))                                      # the Keras-layout HDF5 file, read without h5py
+    x = np.random.default_rng(0).uniform(0, 1, (2, 224, 320, 3)).astype(np.float32)
+    y = wrapper.predict(x)
     assert [t.shape for t in y] == [(2, 7, 10, 3, 25), (2, 14, 20, 3, 25)] and all(np.isfinite(t).all() for t in y)
+    _, w2 = yolonet.yolo_mobilev1([224, 320, 3], 3, 20, alpha=0.5)
+    w2.load_weights(str(ck[0].parent / 'yolo_model.npz'))
+    for a, b in zip(y, w2.predict(x)):
+        np.testing.assert_array_equal(a, b)                               # both checkpoint formats hold the same arrays
+
+
+def test_make_train_reports_an_unusable_pre_ckpt_like_the_reference(tmp_path, capsys):
+    """keras_train.py:52-57: a --pre_ckpt that is not an .h5 file prints `[ ERROR ]  Pre CKPT path is unvalid` and training goes on."""
+    from k210_yolo_framework_amd import training
+    training.cli(['--synthetic', '10', '--model_def', 'yolo_mobilev1', '--depth_multiplier', '0.5', '--batch_size', '4',
+                  '--max_nrof_epochs', '1', '--max_steps', '1', '--log_dir', str(tmp_path), '--pre_ckpt', 'weights.ckpt'])
+    out = capsys.readouterr().out
+    assert '[ ERROR ]  Pre CKPT path is unvalid' in out and 'Save Model as' in out
