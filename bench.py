@@ -2,17 +2,27 @@
 """bench.py — images/sec end-to-end, yolo_mobilev1-0.75, 224x320 network tensor (320x240 frames), B=32/GPU.
 
 One "step" = one pass of the hot path over one batch of synthetic u8 frames ALREADY RESIDENT IN HBM:
-  per-image max normalise -> conv backbone + head (HIP, fp16 storage / fp32 accumulate) ->
+  per-image max normalise -> conv backbone + head (HIP, fp16 activations / fp32 accumulate) ->
   Python-mode decode + per-class NMS (keras_inference.py:94-135 semantics) -> detections in HBM.
+`--streams` (default 3) independent batches are kept in flight (step i on stream i mod 3, own plan and decode scratch);
+the one-batch-in-flight rate is measured in the same run and reported beside it.
 N>1: one process per GPU (torch.distributed / RCCL used only for the barrier + max-over-ranks of the
 timing); images are sharded across ranks, weights replicated, NO data-path collective ("weak" scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (HIP-event timing on the launch stream) and `cpu_baseline` (the CPU oracle, kind "port").
+Timing: W warm-up steps, then regions of EXACTLY K steps each, bracketed by barrier + synchronize on both sides; when one region
+is shorter than 0.25 s (K small) the region is repeated and the MEDIAN region time is used (`timed_regions` says how many).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline        the dominant kernel, HIP-event timing on the launch stream, algorithmic bytes = SURVEY 8(d) in+out fp16
+  cpu_baseline    the CPU path timed on this box's host cores on a bounded sample (oracle port + torch-CPU/oneDNN graph)
+  secondary       SURVEY 8(d) variants measured with the same harness: letterboxed camera frames, frames from pinned host memory
+                  (H2D + D2H of detections inside the step; PCIe-inclusive, never `value`), the f16x2 precision mode, and the
+                  training step of configs[3].
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -25,49 +35,65 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+MIN_REGION_S = 0.25
 
 
-def cpu_baseline(spec, weights, anchors, budget_s=12.0):
-    """The oracle (port of the reference's CPU path: normalise -> conv stack fp32 -> decode+NMS), timed on the
-    host cores on a bounded sample of the same workload."""
+def cpu_baseline(spec, weights, anchors, budget_s=10.0):
+    """The reference's CPU path (normalise -> conv stack fp32 -> decode + per-class NMS) on this box's host cores, B=32 batches
+    of the bench workload, two builds: (port) oracle/yolo_net_ref.c (OpenMP) and (graph) the torch-CPU/oneDNN build of the same
+    Keras graph (oracle/torch_net_ref.py).  The faster one is `value`; both are reported."""
+    import torch
     import oracle
-    from oracle import decode_ref
+    from oracle import decode_ref, torch_net_ref
     plan = spec.compile_plan(weights)
     rng = np.random.default_rng(0)
-    nimg, t_total, n = 4, 0.0, 0
+    B = 32
     cores = os.cpu_count() or 1
-    while t_total < budget_s and n < 64:
-        frames = rng.integers(0, 256, (nimg, *spec.in_hw, 3), dtype=np.uint8)
+    threads = torch.get_num_threads()
+    res = {}
+
+    def chain(fwd):
+        t_total, n = 0.0, 0
+        while t_total < budget_s and n < 256:
+            frames = rng.integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8)
+            t0 = time.perf_counter()
+            outs = fwd(oracle.normalise_u8(frames))
+            decode_ref.decode_batch([o.reshape(B, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors,
+                                    spec.in_hw, spec.in_hw, 0.7, 0.5)
+            t_total += time.perf_counter() - t0
+            n += B
+        return n / t_total, n, t_total
+    res['port'] = chain(lambda x: oracle.net_forward(plan, x, emulate_f16=False, out_ids=spec.outputs))
+    # oneDNN on small convolutions does not scale to every hardware thread of a 2-socket host: probe a few pool sizes, keep the best
+    probe = {}
+    x0 = oracle.normalise_u8(rng.integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8))
+    for nt in sorted({8, 16, 32, 64, min(threads, cores)}):
+        if nt > cores:
+            continue
+        torch.set_num_threads(nt)
+        torch_net_ref.forward(spec, weights, x0[:4], dtype=torch.float32)
         t0 = time.perf_counter()
-        x = oracle.normalise_u8(frames)
-        outs = oracle.net_forward(plan, x, emulate_f16=False, out_ids=spec.outputs)
-        decode_ref.decode_batch([o.reshape(nimg, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors,
-                                spec.in_hw, spec.in_hw, 0.7, 0.5)
-        t_total += time.perf_counter() - t0
-        n += nimg
-    return {'value': round(n / t_total, 2), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} synthetic 224x320 frames through oracle/yolo_net_ref.c (fp32, OpenMP {cores} threads) + '
-                      f'oracle/decode_ref.py, {t_total:.1f} s'}
+        torch_net_ref.forward(spec, weights, x0, dtype=torch.float32)
+        probe[nt] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    budget_s = budget_s / 2
+    res['graph'] = chain(lambda x: list(torch_net_ref.forward(spec, weights, x, dtype=torch.float32).values()))
+    best = max(res, key=lambda k: res[k][0])
+    return {'value': round(res[best][0], 1), 'unit': 'images/sec', 'cores': threads if best == 'graph' else cores,
+            'kind': 'port', 'host_logical_cpus': cores,
+            'sample': f'batches of 32 synthetic 224x320 frames, normalise + fp32 conv stack + decode_ref.py NMS; '
+                      f'oracle/yolo_net_ref.c (OpenMP, {cores} threads): {res["port"][0]:.1f} images/s over {res["port"][1]} frames '
+                      f'({res["port"][2]:.1f} s); torch-CPU oneDNN graph ({threads} threads): {res["graph"][0]:.1f} images/s over '
+                      f'{res["graph"][1]} frames ({res["graph"][2]:.1f} s)',
+            'port_images_per_sec': round(res['port'][0], 1), 'torch_cpu_images_per_sec': round(res['graph'][0], 1)}
 
 
-def train_main(args):
-    """BASELINE configs[3]: yolo_mobilev2 alpha=1.0 VOC training step, 16 images per GPU, YOLO loss, one flat RCCL
-    all-reduce of the gradients.  Not the headline metric; same timing contract (barrier + sync, max over ranks)."""
+def _train_setup(B, rank, world, local):
     import torch
-    from k210_yolo_framework_amd import engine, netspec, shard
+    from k210_yolo_framework_amd import netspec
     from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS
     from k210_yolo_framework_amd.train import Trainer
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    engine.require_gpu()
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
-    B = 16 if args.batch == 32 else args.batch
     spec = netspec.yolo_mobilev2((224, 320, 3), 3, 20, alpha=1.0)
     weights = spec.init_weights(seed=1)
     h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [list(x) for x in spec.out_hw()])
@@ -82,6 +108,26 @@ def train_main(args):
     y_true = [torch.from_numpy(np.stack(y).astype(np.float32)).cuda() for y in ys]
     x = torch.from_numpy(rng.uniform(0, 1, (B, 224, 320, 3)).astype(np.float32)).cuda()
     tr = Trainer(spec, weights, h.anchors, B, lr=5e-4, decay=0.0, device=local, process_group=None, world_size=world)
+    return tr, x, y_true
+
+
+def train_main(args):
+    """BASELINE configs[3]: yolo_mobilev2 alpha=1.0 VOC training step, 16 images per GPU, YOLO loss, one flat RCCL
+    all-reduce of the gradients.  Not the headline metric; same timing contract (barrier + sync, max over ranks)."""
+    import torch
+    from k210_yolo_framework_amd import engine, shard
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    engine.require_gpu()
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+    B = 16 if args.batch == 32 else args.batch
+    tr, x, y_true = _train_setup(B, rank, world, local)
     steps, warm = min(args.steps, 50), min(max(args.warmup, 2), 5)
     for _ in range(warm):
         last = tr.step(x, y_true)
@@ -118,14 +164,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay a captured HIP graph instead of launching eagerly '
-                    '(measured: no gain, the step is GPU-bound; kept as an option)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary measurements (variants, f16x2 mode, training step)')
     ap.add_argument('--streams', type=int, default=3, help='independent batches in flight: step i runs on stream i %% S with its own plan, '
                     'outputs and decode scratch (consecutive steps are independent batches)')
-    ap.add_argument('--letterbox', action='store_true', help='SURVEY 8(d) variant (ii): 240x320 camera frames, letterboxed on the GPU '
-                    '(yk_letterbox_u8) to the 224x320 network tensor inside the timed step')
-    ap.add_argument('--from-host', action='store_true', help='frames start in pinned host memory and cross PCIe inside the timed step '
-                    '(reported for reference; never the headline value)')
+    ap.add_argument('--letterbox', action='store_true', help='SURVEY 8(d) variant (ii) as the timed step: 240x320 camera frames, letterboxed '
+                    'on the GPU (yk_letterbox_u8) to the 224x320 network tensor')
+    ap.add_argument('--from-host', action='store_true', help='frames start in pinned host memory and cross PCIe inside the timed step, '
+                    'detections are copied back (reported for reference; never the headline value)')
+    ap.add_argument('--precision', choices=['f16', 'f16x2'], default='f16')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
     args = ap.parse_args()
@@ -150,42 +196,10 @@ def main():
     spec = netspec.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
     weights = spec.init_weights(seed=1)
     B = args.batch
-    plan = engine.Plan(spec, weights, max_batch=B, device=local)
     cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
     g = torch.Generator(device='cuda').manual_seed(rank)
     frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
-    outs = plan.outputs()
-    cam = None
-    if args.letterbox:
-        cam = torch.randint(0, 256, (B, 240, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
-    host = None
-    if args.from_host:
-        src = cam if cam is not None else frames
-        host = torch.empty(src.shape, dtype=torch.uint8).pin_memory()
-        host.copy_(src)
-
-    def prepare():
-        """-> the [B,224,320,3] u8 network tensor of this step (identity for the headline variant)."""
-        x = host.cuda(non_blocking=True) if host is not None else (cam if cam is not None else frames)
-        return engine.letterbox_u8(x, (224, 320)) if args.letterbox else x
-
-    S = max(1, args.streams)
-    plans = [plan] + [engine.Plan(spec, weights, max_batch=B, device=local) for _ in range(S - 1)]
-    outs_s = [p_.outputs() for p_ in plans]
-    streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
-    for st_ in streams[1 if S == 1 else 0:]:
-        st_.wait_stream(torch.cuda.current_stream())          # frames / weights were produced on the default stream
-    tick = [0]
-
-    def step():
-        i = tick[0] % S
-        tick[0] += 1
-        if S == 1:
-            plan.run_u8(prepare())
-            return engine.decode_py(cfg, outs, B, None, 0.7, 0.5)
-        with torch.cuda.stream(streams[i]):
-            plans[i].run_u8(prepare())
-            return engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
+    cam = torch.randint(0, 256, (B, 240, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -193,74 +207,86 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):
-        step()
-    sync_all()
-    # The step is ~27 back-to-back launches on one stream with no host decision in between; it can be captured
-    # once as a HIP graph and replayed (same kernels, same work).
-    graph = None
-    if args.graph:
-        try:                                         # one graph per in-flight batch, captured on (and replayed to) its own stream
-            graphs = []
-            for i in range(S):
-                st_i = streams[i] if S > 1 else torch.cuda.Stream()
-                st_i.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st_i):
-                    plans[i].run_u8(frames)
-                    engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
-                    st_i.synchronize()
-                    g_i = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_i, stream=st_i):
-                        plans[i].run_u8(frames)
-                        keep = engine.decode_py(cfg, outs_s[i], B, None, 0.7, 0.5)
-                graphs.append((g_i, st_i, keep))
-            torch.cuda.synchronize()
+    class Harness:
+        """S batches in flight; one step = (optional H2D) -> (optional letterbox) -> yk_run_u8 -> yk_decode_py -> (optional D2H)."""
 
-            def replay():
-                i = tick[0] % S
-                tick[0] += 1
-                g_i, st_i, _ = graphs[i]
-                with torch.cuda.stream(st_i):
-                    g_i.replay()
-            for _ in range(2 * S):
-                replay()
+        def __init__(self, S, precision, letterbox=False, from_host=False):
+            self.S, self.letterbox, self.from_host = max(1, S), letterbox, from_host
+            self.plans = [engine.Plan(spec, weights, max_batch=B, device=local, precision=precision) for _ in range(self.S)]
+            self.outs = [p.outputs() for p in self.plans]
+            self.streams = [torch.cuda.Stream() for _ in range(self.S)]
+            for st in self.streams:
+                st.wait_stream(torch.cuda.current_stream())
+            self.tick = 0
+            if from_host:
+                src = cam if letterbox else frames
+                self.host = [torch.empty(src.shape, dtype=torch.uint8).pin_memory() for _ in range(self.S)]
+                for hbuf in self.host:
+                    hbuf.copy_(src)
+                self.copy_streams = [torch.cuda.Stream() for _ in range(self.S)]      # H2D on its own stream per slot: the copy engine
+                self.dev_in = [torch.empty_like(src) for _ in range(self.S)]          # overlaps the previous batch's kernels
+                self.h_dets = [torch.empty((B, 600, 6), dtype=torch.float32).pin_memory() for _ in range(self.S)]
+                self.h_cnt = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(self.S)]
+
+        def step(self):
+            i = self.tick % self.S
+            self.tick += 1
+            st = self.streams[i]
+            if self.from_host:
+                cs = self.copy_streams[i]
+                cs.wait_stream(st)                                   # the slot's previous consumer has finished with dev_in[i]
+                with torch.cuda.stream(cs):
+                    self.dev_in[i].copy_(self.host[i], non_blocking=True)
+                st.wait_stream(cs)
+            with torch.cuda.stream(st):
+                x = self.dev_in[i] if self.from_host else (cam if self.letterbox else frames)
+                if self.letterbox:
+                    x = engine.letterbox_u8(x, (224, 320))
+                self.plans[i].run_u8(x)
+                dets, counts = engine.decode_py(cfg, self.outs[i], B, None, 0.7, 0.5)
+                if self.from_host:
+                    self.h_dets[i].copy_(dets, non_blocking=True)
+                    self.h_cnt[i].copy_(counts, non_blocking=True)
+            return dets, counts
+
+        def measure(self, steps, warmup, min_s=MIN_REGION_S, max_regions=64):
+            for _ in range(max(warmup, 3)):
+                self.step()
+            sync_all()
+            times = []
+            while True:
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.step()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                if dist is not None:
+                    from k210_yolo_framework_amd import shard
+                    dist.barrier()
+                    el = shard.max_over_ranks(el, dist, device='cuda')
+                times.append(el)
+                if sum(times) >= min_s or len(times) >= max_regions:
+                    break
+            return statistics.median(times), len(times)
+
+        def close(self):
             torch.cuda.synchronize()
-            graph = replay
-        except Exception as e:   # capture is an optimisation of the launch path only
-            print(f'[bench] HIP graph capture unavailable ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
-            graph = None
-    run = graph if graph is not None else step
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        from k210_yolo_framework_amd import shard
-        dist.barrier()
-        elapsed = shard.max_over_ranks(elapsed, dist, device='cuda')
+            for p in self.plans:
+                p.close()
+
+    S = max(1, args.streams)
+    head = Harness(S, args.precision, letterbox=args.letterbox, from_host=args.from_host)
+    elapsed, regions = head.measure(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    # the same step with ONE batch in flight (its latency), for reference
-    single_ms = None
-    if S > 1:
-        n1 = min(args.steps, 100)
-        with torch.cuda.stream(streams[0]):
-            for _ in range(5):
-                plans[0].run_u8(frames)
-                engine.decode_py(cfg, outs_s[0], B, None, 0.7, 0.5)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(n1):
-                plans[0].run_u8(frames)
-                engine.decode_py(cfg, outs_s[0], B, None, 0.7, 0.5)
-            torch.cuda.synchronize()
-            single_ms = (time.perf_counter() - t2) / n1 * 1e3
+    single = Harness(1, args.precision, letterbox=args.letterbox, from_host=args.from_host)
+    el1, _ = single.measure(min(args.steps, 100), 5)
+    single_ms = el1 / min(args.steps, 100) * 1e3
 
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream
+        plan = single.plans[0]
         ms = plan.profile(frames, iters=20)
         launches = plan.launches()
         dom = int(np.argmax(ms))
@@ -279,31 +305,82 @@ def main():
                     'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None}
         # HBM bytes of that launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
         # tools/one_step.py + tools/profiles_post.py; counters cannot be collected from inside this process)
-        try:
-            prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')))
-            roof['traffic'] = prof.get(f'{dom}:{name}')
-        except Exception:
-            pass
-        roof.update({'kernel': name, 'avg_us': round(float(ms[dom]) * 1e3, 2),
+        for tag in ('r02', 'r01'):
+            try:
+                prof = json.load(open(ROOT / 'profiles' / f'{tag}_hbm_traffic.json'))
+                if f'{dom}:{name}' in prof:
+                    roof['traffic'] = prof[f'{dom}:{name}']
+                    roof['traffic_source'] = f'profiles/{tag}_hbm_traffic.json'
+                    break
+            except Exception:
+                pass
+        roof.update({'kernel': name, 'avg_us': round(float(ms[dom]) * 1e3, 2), 'algorithmic_bytes_per_launch': int(alg_bytes),
                      'sum_kernels_us': round(float(ms.sum()) * 1e3, 1),
                      'per_kernel_us': {f'{i}:{launches[i][0]}': round(float(ms[i]) * 1e3, 2) for i in range(len(ms))}})
-        tot_bytes = sum(l[2] for l in launches) * B
-        tot_flops = sum(l[1] for l in launches) * B
+        alg_gb = spec.act_elems_per_image() * 2 * B / 1e9                     # in + out of every conv layer once, fp16
+        alg_gflop = 2.0 * spec.macs_per_image() * B / 1e9
+        roof_step_us = alg_gb / HBM_PEAK_GBS * 1e6                            # the whole step is HBM-bound under this model
+        inflight = f'{S} batches in flight' if S > 1 else 'one batch in flight'
         out = {
-            'metric': 'images/sec end-to-end, yolo_mobilev1-0.75 320x240 b32',
+            'metric': f'images/sec end-to-end, yolo_mobilev1-0.75 320x240 b32 ({inflight})',
             'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16 storage / f32 accumulate', 'data': 'synthetic u8 frames resident in HBM, seeded random-init weights',
+            'dtype': 'f16 storage / f32 accumulate' if args.precision == 'f16' else 'f16x2 (compensated fp16 MFMA operands, fp32 storage)',
+            'data': 'synthetic u8 frames resident in HBM, seeded random-init weights',
+            'timed_regions': regions,
             'config': {'workload': 'configs[1]: yolo_mobilev1 alpha=0.75, network tensor 224x320x3 (320x240 frame, SURVEY F1), '
-                                   '20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS',
+                                   f'20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS; {inflight} '
+                                   '(independent batches on separate HIP streams, one plan each)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
-                       'launch_mode': 'hip-graph replay' if graph is not None else 'eager',
-                       'batches_in_flight': S, 'frames': ('240x320 letterboxed on GPU' if args.letterbox else '224x320 native') + (', from pinned host memory' if args.from_host else ', resident in HBM'), 'one_batch_in_flight_ms_per_step': round(single_ms, 4) if single_ms else round(ms_per_step, 4),
-                       'one_batch_in_flight_images_per_sec': round(world * B / ((single_ms or ms_per_step) * 1e-3), 1),
-                       'algorithmic_GB_per_step': round(tot_bytes / 1e9, 4), 'algorithmic_GFLOP_per_step': round(tot_flops / 1e9, 2),
+                       'launch_mode': 'eager', 'batches_in_flight': S, 'precision': args.precision,
+                       'frames': ('240x320 letterboxed on GPU' if args.letterbox else '224x320 native') +
+                                 (', from pinned host memory, detections copied back' if args.from_host else ', resident in HBM'),
+                       'one_batch_in_flight_ms_per_step': round(single_ms, 4),
+                       'one_batch_in_flight_images_per_sec': round(world * B / (single_ms * 1e-3), 1),
+                       'algorithmic_GB_per_step': round(alg_gb, 4), 'algorithmic_GFLOP_per_step': round(alg_gflop, 2),
+                       'step_roofline_us': round(roof_step_us, 1),
+                       'step_frac_of_roofline': round(roof_step_us / (ms_per_step * 1e3), 4),
+                       'one_batch_step_frac_of_roofline': round(roof_step_us / (single_ms * 1e3), 4),
                        'parallelism': f'image-sharded x{world}, no collective'},
             'roofline': roof,
         }
+    head.close()
+    single.close()
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        sec = {}
+        try:
+            def rate(S_, prec, lb, fh, steps=60):
+                hs = Harness(S_, prec, letterbox=lb, from_host=fh)
+                el, _ = hs.measure(steps, 30, min_s=0.25, max_regions=16)
+                hs.close()
+                return round(B * steps / el, 1)
+            sec['letterbox_images_per_sec'] = rate(S, args.precision, True, False)
+            sec['from_host_images_per_sec'] = rate(S, args.precision, False, True)
+            sec['from_host_letterbox_images_per_sec'] = rate(S, args.precision, True, True)
+            sec['from_host_note'] = ('PCIe-inclusive: pinned host u8 frames -> H2D on a copy stream per slot -> run -> decode -> D2H of '
+                                     'detections [32,600,6] + counts; never the headline value')
+            other = 'f16x2' if args.precision == 'f16' else 'f16'
+            sec[f'{other}_images_per_sec'] = rate(S, other, False, False, steps=30)
+            sec[f'{other}_one_batch_images_per_sec'] = rate(1, other, False, False, steps=30)
+        except Exception as e:  # secondary numbers must never take the headline line down
+            sec['error'] = f'{type(e).__name__}: {e}'
+        try:
+            tr, x, y_true = _train_setup(16, 0, 1, local)
+            for _ in range(3):
+                tr.step(x, y_true)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                tr.step(x, y_true)
+            torch.cuda.synchronize()
+            tms = (time.perf_counter() - t0) / 10 * 1e3
+            sec['train'] = {'workload': 'configs[3]: yolo_mobilev2-1.0 224x320 training step, 16 images, fp32', 'ms_per_step': round(tms, 3),
+                            'images_per_sec': round(16 / tms * 1e3, 1)}
+        except Exception as e:
+            sec['train'] = {'error': f'{type(e).__name__}: {e}'}
+        out['secondary'] = sec
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, weights, VOC_ANCHORS)
         print(json.dumps(out))

@@ -1,8 +1,11 @@
-"""Independent torch-CPU arbiter for the conv stack (NOT the oracle, NOT the product).
+"""torch_net_ref.py — CPU ORACLE (test infrastructure, NOT the product path).
 
-Builds the forward pass straight from Keras-layout parameters with torch.nn.functional ops
-and UNFOLDED BatchNorm, so it shares no code with netspec.compile_plan's folding, with
-oracle/yolo_net_ref.c, or with the HIP engine."""
+Independent torch-CPU build of the conv stack (models/yolonet.py, keras_mobilenet*.py layers): the forward pass straight from
+Keras-layout parameters with torch.nn.functional ops and UNFOLDED BatchNorm, so it shares no code with netspec.compile_plan's
+folding, with oracle/yolo_net_ref.c, or with the HIP engine.  Two uses:
+  * float64: the second arbiter tests/test_oracle_net.py checks yolo_net_ref.c against (the TF-1.14 layers are un-vendored, parity
+    with Keras itself is unpinned);
+  * float32: bench.py's `cpu_baseline` leg - the same graph Keras would run on the host cores, on oneDNN."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -10,18 +13,18 @@ import torch.nn.functional as F
 from k210_yolo_framework_amd import netspec as ns
 
 
-def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None):
+def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None, dtype=torch.float64):
     """-> dict tensor_id -> NHWC fp32 numpy for ids in `want` (default: spec.outputs)."""
     want = list(spec.outputs if want is None else want)
     lay = {l.name: l for l in spec.layers}
-    T = {0: torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).double()}
+    T = {0: torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).to(dtype)}
     with torch.no_grad():
         for op in spec.ops:
             x = T[op['in0']]
             t = op['type']
             if t in (ns.OP_CONV, ns.OP_DWCONV):
                 l = lay[op['layer']]
-                k = torch.from_numpy(weights[l.name + '/kernel']).double()
+                k = torch.from_numpy(weights[l.name + '/kernel']).to(dtype)
                 hi, wi = x.shape[2], x.shape[3]
                 ho, wo, _ = spec.tensors[op['out']]
                 kk, st = op['k'], op['stride']
@@ -30,14 +33,14 @@ def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None):
                 xp = F.pad(x, (op['pad_l'], max(pr, 0), op['pad_t'], max(pb, 0)))
                 if t == ns.OP_CONV:
                     w = k.permute(3, 2, 0, 1)                       # HWIO -> OIHW
-                    b = torch.from_numpy(weights[l.name + '/bias']).double() if l.use_bias else None
+                    b = torch.from_numpy(weights[l.name + '/bias']).to(dtype) if l.use_bias else None
                     y = F.conv2d(xp, w, b, stride=st)
                 else:
                     w = k.permute(2, 3, 0, 1)                       # [3,3,C,1] -> [C,1,3,3]
                     y = F.conv2d(xp, w, None, stride=st, groups=x.shape[1])
                 y = y[:, :, :ho, :wo]
                 if l.bn_name:
-                    g, bt, mu, var = (torch.from_numpy(weights[l.bn_name + s]).double()
+                    g, bt, mu, var = (torch.from_numpy(weights[l.bn_name + s]).to(dtype)
                                       for s in ('/gamma', '/beta', '/moving_mean', '/moving_variance'))
                     y = F.batch_norm(y, mu, var, g, bt, training=False, eps=ns.BN_EPS)
                 a = op['act']

@@ -1,11 +1,11 @@
 """The conv-stack oracle (oracle/yolo_net_ref.c) vs an independent torch-CPU float64 build of the
-same Keras layers (tests/torch_ref.py).  Two implementations that share no code must agree."""
+same Keras layers (oracle/torch_net_ref.py).  Two implementations that share no code must agree."""
 import numpy as np
 import pytest
 
 import oracle
 from k210_yolo_framework_amd import netspec as ns
-from tests import torch_ref
+from oracle import torch_net_ref as torch_ref
 
 SURVEY_TABLE = {  # convs, MMAC/img, act elems, weight elems
     ('yolo_mobilev1', (224, 320, 3), 0.75): (32, 732.39, 11351690, 3839376),
