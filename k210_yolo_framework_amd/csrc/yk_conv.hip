@@ -103,14 +103,14 @@ __device__ __forceinline__ half4 epi4(const floatx4 c, const float4 sc, const fl
 
 template <int BM, int BN, int WM, int WN, int OUT, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const igemm_args &a, floatx4 (&acc)[TM][TN], yk_half *lds, int m0, int n0, int tid,
-                                               int lane, int wm, int wn) {
+                                               int lane, int wm, int wn, int zsplit = -1) {
     constexpr int NT = 64 * WM * WN;
     constexpr int CS_LD = BN + 8;
     const int fr = lane & 15;
     // ---- epilogue: lane holds channels n..n+3 (acc regs) of pixel m = lane&15
     const int nl4 = (lane >> 4) * 4;
     if constexpr (OUT == 2) {
-        float *slab = a.slab + (size_t)blockIdx.z * a.M * a.ldn;
+        float *slab = a.slab + (size_t)(zsplit < 0 ? (int)blockIdx.z : zsplit) * a.M * a.ldn;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 16 + fr;
@@ -868,6 +868,8 @@ static int launch_dma(const igemm_args &a, hipStream_t st) {
     return YK_OK;
 }
 
+#include "yk_igemm_pipe.h"
+
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
     const size_t total = (size_t)a.M * (a.ldn >> 2);
     dim3 grid((unsigned)((total + 255) / 256));
@@ -895,6 +897,12 @@ static int launch_cfg(const igemm_args &a, hipStream_t st) {
     };
     static const bool dma_on = getenv("YK_DMA") ? getenv("YK_DMA")[0] != '0' : true;      // LDS-DMA operand tiles (YK_DMA=0: register staging)
     if constexpr (UNI_OK && BK == 64 && !F32 && (BM / 8) % (WM * WN) == 0 && (BN / 8) % (WM * WN) == 0) {
+        static const bool pipe_on = getenv("YK_PIPE") ? getenv("YK_PIPE")[0] != '0' : true;       // multi-stage LDS-DMA ring (yk_igemm_pipe.h)
+        constexpr int NS = 2;   // measured: 3-4 stages cost occupancy and lose 10-20 % everywhere (52x52 128->256: 2 stages 551, 3 stages 457 TF/s)
+        static const int ns_env = getenv("YK_NS") ? atoi(getenv("YK_NS")) : 0;                    // dev sweep
+        if (dma_on && pipe_on && uni && ns_env == 2) return launch_pipe<BM, BN, WM, WN, 2>(a, st);
+        if (dma_on && pipe_on && uni && ns_env == 3) return launch_pipe<BM, BN, WM, WN, 3>(a, st);
+        if (dma_on && pipe_on && uni) return launch_pipe<BM, BN, WM, WN, NS>(a, st);
         if (dma_on && uni && !a.up0) return launch_dma<BM, BN, WM, WN>(a, st);
     }
     static const bool lin_on = getenv("YK_LIN") ? getenv("YK_LIN")[0] != '0' : true;
@@ -998,7 +1006,10 @@ int yk_igemm_split(int cfg, const igemm_args &a) {
     const long target = ((long)c.bm * c.bn >= 128 * 128) ? 512 : 1024;
     long s = (target + tiles - 1) / tiles;
     if (s > nk / 3) s = nk / 3;
-    if (s > 16) s = 16;
+    // the slabs cost HBM traffic twice (written here, read by the finishing pass): measured on the 7x10 / 14x20 head convs the conv
+    // itself takes the same time for 2..10 splits (it is bound by operand traffic through L2, not by parallelism), the finishing
+    // pass grows from 10 to 16 us.  Four splits are enough to have ~3 workgroups per CU.
+    if (s > 4) s = 4;
     return s < 2 ? 1 : (int)s;
 }
 

@@ -1,0 +1,194 @@
+// yk_igemm_pipe.h — the implicit-GEMM conv with a multi-stage LDS-DMA operand pipeline (included by yk_conv.hip).
+//
+// Conv2D 1x1 / 3x3 (stride 1|2) over [up2(src0), src1] as C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_16x16x32_f16, K walked in
+// steps of 64.  Both operand tiles are deposited by `buffer_load_dwordx4 ... lds` (1 KB per wave-instruction = 8 tile rows of
+// 128 B, no staging registers, no ds_write pass) into an NS-deep ring of LDS stages:
+//
+//   prologue   DMA of steps 0 .. NS-2
+//   step kt    s_waitcnt vmcnt((NS-2)*L)      this wave's pieces of step kt have landed (L = DMA instructions per wave and step)
+//              s_barrier                      everybody's have, and everybody is done reading stage (kt-1) % NS
+//              DMA of step kt+NS-1  ->  stage (kt-1) % NS
+//              MFMAs on stage kt % NS
+//
+// so NS-1 steps of loads are in flight under the MFMAs, there is ONE barrier per step and the load queue is never drained inside
+// the loop (a `__syncthreads()` would: hipcc puts vmcnt(0) in front of it while an LDS-DMA is pending - cdna_hip_programming.md,
+// "Pipelining across barriers").  Bank conflicts of the fragment reads are avoided by the XOR swizzle chunk ^= row & 7 applied to
+// the SOURCE address of each lane and to the fragment read (rule 21 of the guide; tools/lds_sim.py, tests/test_lds_model.py).
+// Out-of-image taps, rows >= M, columns >= N and steps past the end of a K split get an offset beyond the descriptor's
+// num_records: the hardware writes zeros, the loop body has no branches.
+// UP: src0 is read through UpSampling2D(2) (yolonet.py:31-38 head, Darknet FPN :167-172): its tap offset is not linear in the tap,
+// the row keeps (y0, x0) instead of a precomputed pointer.
+#pragma once
+
+template <int N>
+__device__ __forceinline__ void yk_wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int OUT, bool UP>
+__global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_args a) {
+    constexpr int NW = WM * WN, BK = 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "8-row DMA groups must divide among the waves");
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, L = A_IT + B_IT;
+    constexpr int STAGE = (BM + BN) * BK;                         // halfs
+    static_assert(NS >= 2 && (NS - 2) * L <= 63, "vmcnt is a 6-bit counter");
+    yk_half *lds = reinterpret_cast<yk_half *>(yk_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    // XCD-aware walk of the whole 3-D grid: workgroup L (dispatch order, x fastest) runs on XCD L % 8; renumber so that an XCD owns a
+    // contiguous run of (K-split, N-tile, M-tile) triples with M fastest - neighbouring M tiles share halo rows and the same weight
+    // panel, and the run's working set (one weight slice + a band of the input) stays inside that XCD's 4 MB L2.
+    // (Tried: cutting M into 8 bands with (K-split, N-tile) as the outer loop inside a band, so that an XCD keeps ONE band of the input:
+    // single layers +2-3 %, the Darknet-53 stack -5 %, the 7x10 head conv much worse - dropped.)
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int L0 = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int v = yk_xcd_tile(L0, gx * gy * gridDim.z);
+    const int vz = v / (gx * gy), vr = v - vz * (gx * gy), vy = vr / gx, vx = vr - vy * gx;
+    const int m0 = vx * BM, n0 = vy * BN;
+    const int Ctp = a.c0p + a.c1p;
+    const int taps = a.ks * a.ks;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int per = (nk_all + a.split_k - 1) / a.split_k;
+    const int kt0 = vz * per;
+    const int nk = min(per, nk_all - kt0);
+    const int rr = lane >> 3, gc = (lane & 7) ^ rr;               // row inside the 8-row group, global chunk this lane fetches
+    const int W0 = a.Wi >> 1;                                     // UP: width of the un-upsampled source
+
+    uint32_t P0[A_IT], P1[A_IT], rmask[A_IT], wro[B_IT];
+    int ry[A_IT], rx[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = m0 + (wid + it * NW) * 8 + rr;
+        const bool ok = m < a.M;
+        const uint32_t mm = ok ? m : 0;
+        const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * (a.Ho * a.Wo);
+        const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
+        const int ry0 = (int)oy * a.stride - a.pad_t, rx0 = (int)ox * a.stride - a.pad_l;
+        ry[it] = ry0;
+        rx[it] = rx0;
+        if constexpr (UP) P0[it] = b * (uint32_t)((a.Hi >> 1) * W0 * a.c0p * 2) + gc * 16u;
+        else P0[it] = b * (uint32_t)(a.Hi * a.Wi * a.c0p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c0p) * 2u + gc * 16u;
+        P1[it] = b * (uint32_t)(a.Hi * a.Wi * a.c1p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c1p - a.c0p) * 2u + gc * 16u;
+        uint32_t msk = 0;
+        for (int t = 0; t < taps; ++t) {
+            const int ky = (a.ks == 3) ? t / 3 : 0, kx = t - ky * a.ks;
+            if (ok && (unsigned)(ry0 + ky) < (unsigned)a.Hi && (unsigned)(rx0 + kx) < (unsigned)a.Wi) msk |= 1u << t;
+        }
+        rmask[it] = msk;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int n = n0 + (wid + it * NW) * 8 + rr;
+        wro[it] = (n < a.N) ? (uint32_t)(n * a.K) * 2u + gc * 16u : YK_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in1 ? a.in1 : a.in0), 0, a.in1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+    const int lim = kt0 + nk;
+    int step = kt0;
+    int tap = (int)yk_div((uint32_t)kt0 * BK, a.fd_ctp);
+    int cin = kt0 * BK - tap * Ctp;
+    auto dma = [&](int stage) {
+        const bool src1 = cin >= a.c0p;
+        const int ky = (a.ks == 3) ? (tap * 11) >> 5 : 0, kx = tap - ky * a.ks;
+        const bool live = (step < lim) && (tap < taps);
+        const uint32_t toff = (uint32_t)((ky * a.Wi + kx) * (src1 ? a.c1p : a.c0p)) * 2u + (uint32_t)cin * 2u;
+        const uint32_t soff = live ? toff : YK_OOB;
+        const uint32_t cs = live ? (uint32_t)cin * 2u : YK_OOB;
+        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
+        yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            uint32_t o;
+            if constexpr (UP) {
+                const uint32_t up = P0[it] + (uint32_t)((((ry[it] + ky) >> 1) * W0 + ((rx[it] + kx) >> 1)) * a.c0p) * 2u + cs;
+                o = src1 ? P1[it] + soff : up;
+            } else {
+                o = (src1 ? P1[it] : P0[it]) + soff;
+            }
+            const uint32_t off = ((rmask[it] >> tap) & 1u) ? o : YK_OOB;
+            lds_ptr_t dst = (lds_ptr_t)(As + (wid + it * NW) * 8 * BK);
+            if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            lds_ptr_t dstb = (lds_ptr_t)(Bs + (wid + it * NW) * 8 * BK);
+            const uint32_t offb = wro[it] + ws;     // a named local: with the sum written inline hipcc's HOST pass silently drops
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, offb, 0, 0, 0);   // the kernel's stub (undefined symbol at load)
+        }
+        ++step;
+        cin += BK;
+        const bool wrap = cin >= Ctp;
+        cin = wrap ? 0 : cin;
+        tap += wrap ? 1 : 0;
+    };
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, sw = fr & 7, fq = lane >> 4;
+    auto compute = [&](int stage) {
+        const yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 4 + fq) ^ sw) * 8;             // swizzled 16-byte chunk of this lane's fragment
+            half8 wf[TN], xf[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * BK + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * BK + ch);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nk > 0) {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) dma(s);                   // steps past `lim` deposit zeros and keep the vmcnt arithmetic uniform
+        int rd = 0, wr = NS - 1;                                   // stage read this step / stage refilled this step
+        for (int kt = 0; kt < nk; ++kt) {
+            yk_wait_vm_lgkm0<(NS - 2) * L>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            dma(wr);
+            compute(rd);
+            rd = (rd + 1 == NS) ? 0 : rd + 1;
+            wr = (wr + 1 == NS) ? 0 : wr + 1;
+        }
+        yk_wait_vm_lgkm0<0>();                                     // drain the dead prefetches before LDS is reused by the epilogue
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn, vz);
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_pipe(const igemm_args &a, hipStream_t st) {
+    constexpr size_t ring = (size_t)NS * (BM + BN) * 64 * 2, ct = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t ldsd = ring > ct ? ring : ct;
+    dim3 g2((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
+    auto go = [&](auto kern) {
+        if (ldsd > 64 * 1024) {
+            static bool done = false;
+            if (!done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
+                done = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, g2, dim3(64 * WM * WN), ldsd, st, a);
+    };
+    if (a.up0) {
+        if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, true>);
+        else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, true>);
+    } else {
+        if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false>);
+        else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false>);
+    }
+    return YK_OK;
+}
