@@ -67,7 +67,12 @@ struct igemm_args {
     float dw_slope, dw_cap;
     int lda_pad;                // LDS pitch padding (halfs) of the fused kernels' depthwise tile (yk_fused_pad())
     long long *dbg;             // dev instrumentation: per-workgroup phase timestamps (null in production)
+    // patch geometry of the LDS-DMA staged fused kernel (yk_fused_dma.h), fixed at plan creation for max_batch so that an image's
+    // arithmetic never depends on how many images share the launch
+    int fp_npw, fp_ks, fp_mt, fp_tr, fp_tc, fp_ns;
+    unsigned fp_lds;
 };
+void yk_fdma_fill(igemm_args &a);   // computes the fp_* fields (a.M = max_batch * Ho * Wo)
 enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_64x80,
        IGEMM_F32_128x64, IGEMM_128x64K64, IGEMM_64x128, IGEMM_64x192, IGEMM_NUM };
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st);
@@ -86,7 +91,7 @@ const char *yk_igemm_name(int cfg);
 enum { FUSED_128x48 = 0, FUSED_128x96, FUSED_64x192, FUSED_32x192,
        WIDE_4x3_T4, WIDE_2x6_T4, WIDE_2x6_T2, WIDE_1x12_T4, WIDE_1x12_T2, WIDE_1x12_T2_D12, LR_T1, LR_T2,
        WAVE_T1_N3, WAVE_T2_N3, WAVE_T1_N6, WAVE_T2_N6, WAVE_T1_N12, WAVE_T2_N12,
-       WIDE_1x12_T3_D12, WIDE_1x12_T5_D12, WIDE_1x12_T5, WIDE_1x12_T9, FUSED_NUM };
+       WIDE_1x12_T3_D12, WIDE_1x12_T5_D12, WIDE_1x12_T5, WIDE_1x12_T9, FUSED_DMA, FUSED_NUM };
 bool yk_igemm_fused_ok(int c0p, int cout);
 int yk_igemm_fused_pick(const igemm_args &a);
 const char *yk_igemm_fused_name(int cfg);

@@ -1956,6 +1956,8 @@ static int launch_fused(const igemm_args &a, hipStream_t st) {
     return YK_OK;
 }
 
+#include "yk_fused_dma.h"
+
 bool yk_igemm_fused_ok(int c0p, int cout) {
     // the whole K extent of the depthwise tile must fit LDS at the smallest BM (32 rows)
     const int Kp = (c0p + 31) & ~31;
@@ -1963,6 +1965,14 @@ bool yk_igemm_fused_ok(int c0p, int cout) {
 }
 int yk_igemm_fused_pick(const igemm_args &a) {
     const int G = a.c0p >> 3;
+    // small-spatial blocks (<= 28x40 at batch 32): the LDS-DMA staged kernel (yk_fused_dma.h)
+    static const bool fdma_on = getenv("YK_FDMA") ? getenv("YK_FDMA")[0] != '0' : true;
+    if (fdma_on && a.c0p >= 96 && a.M <= 65536) {
+        // measured against fused_wide at batch 32: 96->192 s2 21.3 -> 18.5 us, 384->384 17.7 -> 15.7, 384->768 s2 17.7 -> 14.4; the
+        // 192->192 block (448 patches = two rounds of one 768-thread workgroup per CU) 18.1 -> 20.9: keeps the old kernel
+        const fdma_plan pl = yk_fdma_plan(a);
+        if (pl.npw && (pl.rounds == 1 || a.c0p <= 96)) return FUSED_DMA;
+    }
     static const bool wide = getenv("YK_WIDE") ? getenv("YK_WIDE")[0] != '0' : true;
     static const int wavek = getenv("YK_WAVE") ? atoi(getenv("YK_WAVE")) : 0;   // 0 off, 1/2 = TM
     if (wavek && a.c0p <= 192 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) {
@@ -2003,7 +2013,7 @@ int yk_igemm_fused_pick(const igemm_args &a) {
 }
 const char *yk_igemm_fused_name(int cfg) {
     static const char *n[] = {"fused_128x48", "fused_128x96", "fused_64x192", "fused_32x192", "wide_256x48", "wide_128x96",
-                              "wide_64x96", "wide_64x192", "wide_32x192", "wide_32x192d12", "lr_64", "lr_128", "wave16_n48", "wave32_n48", "wave16_n96", "wave32_n96", "wave16_n192", "wave32_n192", "wide_48x192d12", "wide_80x192d12", "wide_80x192", "wide_144x192"};
+                              "wide_64x96", "wide_64x192", "wide_32x192", "wide_32x192d12", "lr_64", "lr_128", "wave16_n48", "wave32_n48", "wave16_n96", "wave32_n96", "wave16_n192", "wave32_n192", "wide_48x192d12", "wide_80x192d12", "wide_80x192", "wide_144x192", "fdma"};
     return (cfg >= 0 && cfg < FUSED_NUM) ? n[cfg] : "?";
 }
 int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st) {
@@ -2030,6 +2040,7 @@ int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st) {
     case WAVE_T2_N6: return launch_wave<2, 6>(a, st);
     case WAVE_T1_N12: return launch_wave<1, 12>(a, st);
     case WAVE_T2_N12: return launch_wave<2, 12>(a, st);
+    case FUSED_DMA: return yk_launch_fdma(a, st);
     }
     yk_set_error("yk_launch_igemm_fused: bad config %d", cfg);
     return YK_ERR_ARG;

@@ -448,6 +448,24 @@ extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops,
             g.M = max_batch * Y.h * Y.w;   // for config choice; patched per run
             l.cfg = dwo ? yk_igemm_fused_pick(g) : yk_igemm_pick(g, f32);
             l.out_f32 = f32;
+            if (dwo && l.cfg == FUSED_DMA) {
+                yk_fdma_fill(g);
+                // the LDS-DMA staged kernel reads its pointwise panel in MFMA fragment order: [16-channel slice][k-step of 32][lane][8],
+                // element = W[slice*16 + (lane & 15)][kstep*32 + (lane >> 4)*8 + e]; one wave-load = 1 KB contiguous
+                const int Kp = (c0p + 31) & ~31, nkf = Kp / 32, nsl = (co + 15) / 16;
+                std::vector<uint16_t> wf((size_t)nsl * nkf * 512, 0);
+                for (int sl = 0; sl < nsl; ++sl)
+                    for (int ks2 = 0; ks2 < nkf; ++ks2)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = sl * 16 + (ln & 15), k = ks2 * 32 + (ln >> 4) * 8 + e;
+                                if (n < co && k < g.K) wf[(((size_t)sl * nkf + ks2) * 64 + ln) * 8 + e] = w[(size_t)n * g.K + k];
+                            }
+                void *dwf;
+                if ((rc = upload(p, &dwf, wf.data(), wf.size() * 2))) return fail(rc);
+                g.w = (const yk_half *)dwf;
+                g.w_bytes = (uint32_t)(wf.size() * 2);
+            }
             if (!dwo && env_flag("YK_SPLITK", true)) {
                 g.split_k = yk_igemm_split(l.cfg, g);
                 if (g.split_k > 1) {
