@@ -296,3 +296,4 @@ static int yk_launch_fdma(const igemm_args &a, hipStream_t st) {
     if (pl.npw == 2 && pl.ks == 6) return launch_fdma_t<2, 6, 3>(a, pl, st);
     return launch_fdma_t<2, 12, 3>(a, pl, st);
 }
+
