@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict
     *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
 }
 
+#include "yk_gemm_f32.h"
+
 extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B,
                            int ldb, float beta, float *C, int ldc, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) {
@@ -151,7 +153,11 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
         g.ws = (float *)yk_scratch(dev, stream, 14, sizeof(float) * (size_t)s * M * N);
         if (!g.ws) return YK_ERR_NOMEM;
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((M + 63) / 64, (N + 63) / 64, s), dim3(256), 0, st, g);
+    const dim3 grid((M + 63) / 64, (N + 63) / 64, s);
+    if (!transA && transB) launch_gemm_v2<false, true>(g, grid, st);          // forward
+    else if (!transA && !transB) launch_gemm_v2<false, false>(g, grid, st);   // data gradient
+    else if (transA && !transB) launch_gemm_v2<true, false>(g, grid, st);     // weight gradient
+    else hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
     if (s > 1) {
         const size_t tot = (size_t)M * N;
         hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta, C,

@@ -36,7 +36,7 @@ class Trainer:
     def __init__(self, spec: ns.NetSpec, weights: Dict[str, np.ndarray], anchors: np.ndarray, per_rank_batch: int,
                  obj_thresh: float = 0.7, iou_thresh: float = 0.5, obj_weight: float = 1.0, noobj_weight: float = 1.0,
                  wh_weight: float = 1.0, lr: float = 5e-4, decay: float = 0.0, device: int = 0, process_group=None,
-                 world_size: int = 1):
+                 world_size: int = 1, use_graph: bool = True):
         import torch
         engine.require_gpu()
         self.torch = torch
@@ -76,6 +76,13 @@ class Trainer:
         self.counts = [torch.zeros(3, dtype=torch.float32, device=self.dev) for _ in spec.outputs]
         self.saved: Dict[int, dict] = {}
         self.T: Dict[int, "torch.Tensor"] = {}
+        # forward + loss + backward is ~800 launches whose arguments never change from step to step: after one eager step it is
+        # captured as a HIP graph and replayed (same kernels, same order, same buffers -> bitwise the same results; measured 7.8 ->
+        # 6.7 ms per step for yolo_mobilev2-1.0 at 16 images).  Adam stays outside: its step counter is a launch argument.
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._gx = self._gy = self._gres = self._side = None
+        self._eager_steps = 0
 
     # ------------------------------------------------------------------ parameters
     def view(self, buf, name):
@@ -337,10 +344,44 @@ class Trainer:
         reg = self.regulariser(add_grad=self.world == 1)
         return dict(layers=parts, reg=reg)
 
+    def _loss_and_grads_replayed(self, x_nhwc, y_true):
+        """loss_and_grads through a captured HIP graph (after one eager step that also warms allocator and scratch buffers)."""
+        torch = self.torch
+        if not self.use_graph:
+            return self.loss_and_grads(x_nhwc, y_true)
+        if self._graph is None:
+            # both the eager first step and the capture run on one dedicated stream: the library's scratch buffers are keyed by
+            # stream and must already have their final size when the capture starts (an allocation would invalidate it)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            side, cur = self._side, torch.cuda.current_stream()
+            side.wait_stream(cur)
+            if self._eager_steps < 1:
+                self._eager_steps += 1
+                with torch.cuda.stream(side):
+                    r = self.loss_and_grads(x_nhwc, y_true)
+                cur.wait_stream(side)
+                return r
+            self._gx = x_nhwc.clone()
+            self._gy = [y.clone() for y in y_true]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self._gres = self.loss_and_grads(self._gx, self._gy)
+            cur.wait_stream(side)
+            self._graph = g
+            # the capture itself does not execute: fall through to a replay with the current batch
+        self._gx.copy_(x_nhwc)
+        for d, s_ in zip(self._gy, y_true):
+            d.copy_(s_)
+        self._graph.replay()
+        return self._gres
+
     def step(self, x_nhwc, y_true: Sequence["torch.Tensor"]) -> Dict[str, float]:
         """model.fit's inner step (keras_train.py:94).  Returns python floats (one device->host sync)."""
         torch = self.torch
-        r = self.loss_and_grads(x_nhwc, y_true)
+        r = self._loss_and_grads_replayed(x_nhwc, y_true)
         if self.world > 1:
             import torch.distributed as dist
             from .shard import allreduce_gradients
