@@ -10,6 +10,15 @@
 
 #define YK_WAVE 64
 
+// Tuning switches (YK_IGEMM_FORCE, YK_SPLIT_FORCE, YK_PIPE, ...) exist only in development builds (`make DEV=1`, -DYK_DEV): the
+// shipped library never reads the environment on its launch path.
+#include <stdlib.h>
+#ifdef YK_DEV
+static inline const char *yk_dev_env(const char *name) { return getenv(name); }
+#else
+static inline const char *yk_dev_env(const char *) { return nullptr; }
+#endif
+
 void yk_set_error(const char *fmt, ...);
 
 #define YK_HIP(call)                                                                           \

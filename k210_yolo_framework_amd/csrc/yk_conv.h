@@ -89,9 +89,7 @@ const char *yk_igemm_name(int cfg);
 // fused DepthwiseConv2D(3x3)+BN+act -> Conv2D(1x1)+BN+act: the depthwise tile is produced straight
 // into LDS (never written to HBM) and consumed as the MFMA pixel operand; weights stream from L2.
 enum { FUSED_128x48 = 0, FUSED_128x96, FUSED_64x192, FUSED_32x192,
-       WIDE_4x3_T4, WIDE_2x6_T4, WIDE_2x6_T2, WIDE_1x12_T4, WIDE_1x12_T2, WIDE_1x12_T2_D12, LR_T1, LR_T2,
-       WAVE_T1_N3, WAVE_T2_N3, WAVE_T1_N6, WAVE_T2_N6, WAVE_T1_N12, WAVE_T2_N12,
-       WIDE_1x12_T3_D12, WIDE_1x12_T5_D12, WIDE_1x12_T5, WIDE_1x12_T9, FUSED_DMA, FUSED_NUM };
+       WIDE_4x3_T4, WIDE_2x6_T4, WIDE_2x6_T2, WIDE_1x12_T4, WIDE_1x12_T2, LR_T1, LR_T2, WIDE_1x12_T5, WIDE_1x12_T9, FUSED_DMA, FUSED_NUM };
 bool yk_igemm_fused_ok(int c0p, int cout);
 int yk_igemm_fused_pick(const igemm_args &a);
 const char *yk_igemm_fused_name(int cfg);

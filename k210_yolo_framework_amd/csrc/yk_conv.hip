@@ -725,149 +725,6 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_lin_kernel(const igemm_arg
     igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
 }
 
-// =====================================================================================
-// igemm_dma_kernel: igemm_lin_kernel with the operand tiles filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs,
-// no ds_write pass (13 cycles per wave-instruction, MI355X_MICROARCH.md), half the registers.  A wave-instruction deposits 64 x 16 B
-// at a wave-uniform LDS base + lane*16, i.e. 8 tile rows of BK = 64 halfs, unpadded; bank conflicts of the fragment reads are
-// avoided by the XOR swizzle tools/lds_sim.py derives for a 128-byte pitch (chunk ^= row & 7), applied on BOTH sides: the lane that
-// lands at (row, chunk) fetches global chunk (chunk ^ row&7), the fragment read of logical chunk q goes to (q ^ row&7)
-// (cdna_hip_programming.md rule 21).  Two LDS stages; the DMA of step k+1 flies under the MFMAs of step k and is retired by the
-// vmcnt(0) in front of the barrier that ends the step, so a stage is read one barrier after its DMA was waited for.
-// Measured (conv3x3 256->512, 26x26, B=16): 64x128x64 tile 461 -> 558 TFLOP/s, 64x64x64 438 -> 451; VGPRs 110 -> 44+16, occupancy 4 -> 8.
-// =====================================================================================
-template <int BM, int BN, int WM, int WN, int OUT>
-__global__ void __launch_bounds__(64 * WM * WN) igemm_dma_kernel(const igemm_args a) {
-    constexpr int NW = WM * WN, BK = 64;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "8-row DMA groups must divide among the waves");
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
-    constexpr int STAGE = (BM + BN) * BK;                         // halfs
-    yk_half *lds = reinterpret_cast<yk_half *>(yk_smem);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid % WN;
-    const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
-    const int Ctp = a.c0p + a.c1p;
-    const int taps = a.ks * a.ks;
-    const int nk_all = (a.K + BK - 1) / BK;
-    const int per = (nk_all + a.split_k - 1) / a.split_k;
-    const int kt0 = blockIdx.z * per;
-    const int nk = min(per, nk_all - kt0);
-    const int rr = lane >> 3, gc = (lane & 7) ^ rr;               // row inside the 8-row group, global chunk this lane fetches
-
-    uint32_t P0[A_IT], P1[A_IT], rmask[A_IT], wro[B_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + (wid + it * NW) * 8 + rr;
-        const bool ok = m < a.M;
-        const uint32_t mm = ok ? m : 0;
-        const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * (a.Ho * a.Wo);
-        const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
-        const int ry0 = (int)oy * a.stride - a.pad_t, rx0 = (int)ox * a.stride - a.pad_l;
-        P0[it] = b * (uint32_t)(a.Hi * a.Wi * a.c0p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c0p) * 2u + gc * 16u;
-        P1[it] = b * (uint32_t)(a.Hi * a.Wi * a.c1p * 2) + (uint32_t)((ry0 * a.Wi + rx0) * a.c1p - a.c0p) * 2u + gc * 16u;
-        uint32_t msk = 0;
-        for (int t = 0; t < taps; ++t) {
-            const int ky = (a.ks == 3) ? t / 3 : 0, kx = t - ky * a.ks;
-            if (ok && (unsigned)(ry0 + ky) < (unsigned)a.Hi && (unsigned)(rx0 + kx) < (unsigned)a.Wi) msk |= 1u << t;
-        }
-        rmask[it] = msk;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int n = n0 + (wid + it * NW) * 8 + rr;
-        wro[it] = (n < a.N) ? (uint32_t)(n * a.K) * 2u + gc * 16u : YK_OOB;
-    }
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in0, 0, a.in0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in1 ? a.in1 : a.in0), 0, a.in1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
-    typedef __attribute__((address_space(3))) void *lds_ptr_t;
-
-    const int lim = kt0 + nk;
-    int step = kt0;
-    int tap = (int)yk_div((uint32_t)kt0 * BK, a.fd_ctp);
-    int cin = kt0 * BK - tap * Ctp;
-    auto dma = [&](int stage) {
-        const bool src1 = cin >= a.c0p;
-        const int ky = (a.ks == 3) ? (tap * 11) >> 5 : 0, kx = tap - ky * a.ks;
-        const bool live = (step < lim) && (tap < taps);
-        const uint32_t toff = (uint32_t)((ky * a.Wi + kx) * (src1 ? a.c1p : a.c0p)) * 2u + (uint32_t)cin * 2u;
-        const uint32_t soff = live ? toff : YK_OOB;
-        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
-        yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const uint32_t o = (src1 ? P1[it] : P0[it]) + soff;
-            const uint32_t off = ((rmask[it] >> tap) & 1u) ? o : YK_OOB;
-            lds_ptr_t dst = (lds_ptr_t)(As + (wid + it * NW) * 8 * BK);
-            if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            lds_ptr_t dstb = (lds_ptr_t)(Bs + (wid + it * NW) * 8 * BK);
-            const uint32_t offb = wro[it] + ws;     // a named local: with the sum written inline hipcc's HOST pass silently drops
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, offb, 0, 0, 0);   // the kernel's stub (undefined symbol at load)
-        }
-        ++step;
-        cin += BK;
-        const bool wrap = cin >= Ctp;
-        cin = wrap ? 0 : cin;
-        tap += wrap ? 1 : 0;
-    };
-    floatx4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, sw = fr & 7, fq = lane >> 4;
-    auto compute = [&](int stage) {
-        const yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((ks * 4 + fq) ^ sw) * 8;             // swizzled 16-byte chunk of this lane's fragment
-            half8 wf[TN], xf[TM];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * BK + ch);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * BK + ch);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-    };
-    if (nk > 0) {
-        dma(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this wave's DMA has landed
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            dma((kt + 1) & 1);                                     // next step (zeros past the end) under this step's MFMAs
-            compute(kt & 1);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __syncthreads();
-        }
-    }
-    igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn);
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_dma(const igemm_args &a, hipStream_t st) {
-    constexpr size_t st2 = (size_t)2 * (BM + BN) * 64 * 2, ct = (size_t)BM * (BN + 8) * 2;
-    constexpr size_t ldsd = st2 > ct ? st2 : ct;
-    dim3 g2((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
-    if (ldsd > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_dma_kernel<BM, BN, WM, WN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_dma_kernel<BM, BN, WM, WN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
-            done = true;
-        }
-    }
-    if (a.split_k > 1) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 2>), g2, dim3(64 * WM * WN), ldsd, st, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, 0>), g2, dim3(64 * WM * WN), ldsd, st, a);
-    return YK_OK;
-}
-
 #include "yk_igemm_pipe.h"
 
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
@@ -881,7 +738,7 @@ int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int BK, bool F32, bool UNI_OK = false>
 static int launch_cfg(const igemm_args &a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
-    static const bool uni_on = getenv("YK_UNI") ? getenv("YK_UNI")[0] != '0' : true;
+    static const bool uni_on = yk_dev_env("YK_UNI") ? yk_dev_env("YK_UNI")[0] != '0' : true;
     const bool uni = uni_on && UNI_OK && ((a.c0p + a.c1p) % BK == 0) && (a.c0p % BK == 0) && a.in0_bytes < YK_OOB && a.in1_bytes < YK_OOB;
     constexpr size_t stages = (size_t)2 * (BM + BN) * (BK + YK_LDPAD) * 2, ctile = F32 ? 0 : (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stages > ctile ? stages : ctile;
@@ -895,23 +752,22 @@ static int launch_cfg(const igemm_args &a, hipStream_t st) {
         }
         hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, a);
     };
-    static const bool dma_on = getenv("YK_DMA") ? getenv("YK_DMA")[0] != '0' : true;      // LDS-DMA operand tiles (YK_DMA=0: register staging)
+    static const bool dma_on = yk_dev_env("YK_DMA") ? yk_dev_env("YK_DMA")[0] != '0' : true;      // LDS-DMA operand tiles (YK_DMA=0: register staging)
     if constexpr (UNI_OK && BK == 64 && !F32 && (BM / 8) % (WM * WN) == 0 && (BN / 8) % (WM * WN) == 0) {
-        static const bool pipe_on = getenv("YK_PIPE") ? getenv("YK_PIPE")[0] != '0' : true;       // multi-stage LDS-DMA ring (yk_igemm_pipe.h)
+        static const bool pipe_on = yk_dev_env("YK_PIPE") ? yk_dev_env("YK_PIPE")[0] != '0' : true;       // multi-stage LDS-DMA ring (yk_igemm_pipe.h)
         constexpr int NS = 2;   // measured: 3-4 stages cost occupancy and lose 10-20 % everywhere (52x52 128->256: 2 stages 551, 3 stages 457 TF/s)
-        static const int ns_env = getenv("YK_NS") ? atoi(getenv("YK_NS")) : 0;                    // dev sweep
+        static const int ns_env = yk_dev_env("YK_NS") ? atoi(yk_dev_env("YK_NS")) : 0;                    // dev sweep
         if (dma_on && pipe_on && uni && ns_env == 2) return launch_pipe<BM, BN, WM, WN, 2>(a, st);
         if (dma_on && pipe_on && uni && ns_env == 3) return launch_pipe<BM, BN, WM, WN, 3>(a, st);
         if (dma_on && pipe_on && uni) return launch_pipe<BM, BN, WM, WN, NS>(a, st);
-        if (dma_on && uni && !a.up0) return launch_dma<BM, BN, WM, WN>(a, st);
     }
-    static const bool lin_on = getenv("YK_LIN") ? getenv("YK_LIN")[0] != '0' : true;
+    static const bool lin_on = yk_dev_env("YK_LIN") ? yk_dev_env("YK_LIN")[0] != '0' : true;
     constexpr bool LIN_OK = UNI_OK && ((BM * (BK / 8)) % (64 * WM * WN) == 0) && ((BN * (BK / 8)) % (64 * WM * WN) == 0);
     if constexpr (LIN_OK) {
         if (uni && lin_on && !a.up0) {
             // prefetch depth: 4 k-steps in flight where a step's staging registers are cheap (<= 16 VGPRs)
             constexpr int PF = ((BM + BN) * (BK / 8) / (64 * WM * WN) <= 4) ? 4 : 2;
-            static const int pf_env = getenv("YK_PF") ? atoi(getenv("YK_PF")) : 0;
+            static const int pf_env = yk_dev_env("YK_PF") ? atoi(yk_dev_env("YK_PF")) : 0;
             if (PF == 4 && pf_env != 2) {
                 if (a.split_k > 1) go(igemm_lin_kernel<BM, BN, WM, WN, BK, 2, PF>);
                 else go(igemm_lin_kernel<BM, BN, WM, WN, BK, F32 ? 1 : 0, PF>);
@@ -961,7 +817,7 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
 }
 
 int yk_fused_pad() {
-    static const int p = getenv("YK_FPAD") ? atoi(getenv("YK_FPAD")) : 16;
+    static const int p = yk_dev_env("YK_FPAD") ? atoi(yk_dev_env("YK_FPAD")) : 16;
     return (p == 8 || p == 16 || p == 24) ? p : 16;
 }
 
@@ -969,8 +825,8 @@ const char *yk_igemm_name(int cfg) { return (cfg >= 0 && cfg < IGEMM_NUM) ? g_cf
 
 int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     if (out_f32) return a.N <= 80 ? IGEMM_F32_64x80 : IGEMM_F32_128x64;
-    if (a.K >= (getenv("YK_FORCE_MINK") ? atoi(getenv("YK_FORCE_MINK")) : 1024)) {   // tuning sweep hook (tools/igemm_sweep.py)
-        const char *f = getenv("YK_IGEMM_FORCE");
+    if (a.K >= (yk_dev_env("YK_FORCE_MINK") ? atoi(yk_dev_env("YK_FORCE_MINK")) : 1024)) {   // tuning sweep hook (tools/igemm_sweep.py)
+        const char *f = yk_dev_env("YK_IGEMM_FORCE");
         if (f && f[0]) {
             const int c = atoi(f);
             if (c >= 0 && c < IGEMM_NUM && c != IGEMM_F32_64x80 && c != IGEMM_F32_128x64 && a.N % g_cfg[c].bn == 0) return c;
@@ -999,7 +855,7 @@ int yk_igemm_split(int cfg, const igemm_args &a) {
     const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
     const int nk = (a.K + c.bk - 1) / c.bk;
     if (a.K >= 1024) {
-        const char *f = getenv("YK_SPLIT_FORCE");
+        const char *f = yk_dev_env("YK_SPLIT_FORCE");
         if (f && f[0]) return std::max(1, std::min(atoi(f), nk));
     }
     if (tiles >= 384 || nk < 6) return 1;
@@ -1165,7 +1021,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const first_args a) {
 }
 
 int yk_launch_first(const first_args &a, hipStream_t st) {
-    static const bool mfma_on = getenv("YK_STEM_MFMA") ? getenv("YK_STEM_MFMA")[0] != '0' : true;
+    static const bool mfma_on = yk_dev_env("YK_STEM_MFMA") ? yk_dev_env("YK_STEM_MFMA")[0] != '0' : true;
     if (mfma_on && !a.in_f32 && a.wm && a.Cout <= 32 && a.outp % 4 == 0 && (a.Ho * a.Wo) % 256 == 0 &&
         (size_t)a.Hi * a.Wi * 3 < YK_OOB) {
         hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)(a.B * ((a.Ho * a.Wo) >> 8))), dim3(256), 0, st, a);
@@ -1224,7 +1080,7 @@ __global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__
 
 int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st) {
     const int vec_ok = (per_image % 16 == 0) && ((uintptr_t)frames % 16 == 0);
-    static const int parts = getenv("YK_MAXP_RT") ? std::max(1, std::min(YK_MAXP, atoi(getenv("YK_MAXP_RT")))) : YK_MAXP;   // unused slots stay 0
+    static const int parts = yk_dev_env("YK_MAXP_RT") ? std::max(1, std::min(YK_MAXP, atoi(yk_dev_env("YK_MAXP_RT")))) : YK_MAXP;   // unused slots stay 0
     hipLaunchKernelGGL(u8_max_kernel, dim3(parts, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
     return YK_OK;
 }
@@ -1784,145 +1640,6 @@ static int launch_lr(const igemm_args &a, hipStream_t st) {
     return YK_OK;
 }
 
-// -------------------------------------------------------------------------------------
-// "wave" variant: barrier-free, every wavefront is autonomous.  The MFMA pixel-operand layout of
-// v_mfma_f32_16x16x32_f16 is  lane -> (pixel = lane&15, channel octet = lane>>4): exactly one
-// depthwise work item (pixel, 8 channels).  So each lane computes the depthwise result of ITS
-// fragment in registers and feeds it straight to the MFMA — the depthwise tile never exists in LDS
-// or HBM, there is no __syncthreads() after the prologue, and waves drift freely so one wave's
-// loads overlap another's math.  Pointwise weights (N x K fp16, <= 72 KB) are re-read per wave from L1/L2.
-// One wave = 16*TM consecutive output pixels x all N = 16*TN channels.
-// -------------------------------------------------------------------------------------
-template <int TM, int TN>
-__global__ void __launch_bounds__(256) fused_wave_kernel(const igemm_args a) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int Cp = a.c0p, nk = (Cp + 31) >> 5;
-    yk_half *Ws = reinterpret_cast<yk_half *>(yk_smem);          // depthwise weights [9][Cp]
-    float *Sb = reinterpret_cast<float *>(Ws + (size_t)9 * Cp);  // depthwise scale[Cp], bias[Cp]
-    for (int v = tid; v < 9 * (Cp >> 3); v += 256)
-        *reinterpret_cast<half8 *>(Ws + v * 8) = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)v * 8);
-    for (int v = tid; v < Cp; v += 256) {
-        Sb[v] = a.dw_scale[v];
-        Sb[Cp + v] = a.dw_bias[v];
-    }
-    __syncthreads();                                              // the only block-level barrier
-
-    const int fr = lane & 15, kg = lane >> 4;
-    const int wave = yk_xcd_tile(blockIdx.x, gridDim.x) * 4 + wid;
-    const int mb = wave * 16 * TM;
-    if (mb >= a.M) return;
-    const int hw = a.Ho * a.Wo;
-    const yk_half *base[TM];
-    int iy0[TM], ix0[TM];
-    bool valid[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = mb + i * 16 + fr;
-        valid[i] = m < a.M;
-        const uint32_t mm = valid[i] ? m : 0;
-        const uint32_t b = yk_div(mm, a.fd_hw), rem = mm - b * hw;
-        const uint32_t oy = yk_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
-        iy0[i] = (int)oy * a.dw_stride - a.dw_pad_t;
-        ix0[i] = (int)ox * a.dw_stride - a.dw_pad_l;
-        base[i] = a.in0 + (size_t)b * a.dw_Hi * a.dw_Wi * Cp;
-    }
-    floatx4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int c0 = (kt * 4 + kg) * 8;                         // this lane's channel octet
-        const bool cv = c0 < Cp;
-        // pointwise weight fragments of this k-step (independent of the depthwise result)
-        half8 wf[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = j * 16 + fr;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n < a.N && c0 < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + c0);
-            wf[j] = v;
-        }
-        // depthwise taps of all TM pixels of this lane: 9*TM loads in flight
-        u32x4 x[TM][9];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-                    u32x4 v = {0, 0, 0, 0};
-                    if (cv && valid[i] && (unsigned)iy < (unsigned)a.dw_Hi && (unsigned)ix < (unsigned)a.dw_Wi)
-                        v = *reinterpret_cast<const u32x4 *>(base[i] + (size_t)(iy * a.dw_Wi + ix) * Cp + c0);
-                    x[i][ky * 3 + kx] = v;
-                }
-        half8 xf[TM];
-        const int cc = cv ? c0 : 0;
-        const float4 sc0 = *reinterpret_cast<const float4 *>(Sb + cc), sc1 = *reinterpret_cast<const float4 *>(Sb + cc + 4);
-        const float4 bs0 = *reinterpret_cast<const float4 *>(Sb + Cp + cc), bs1 = *reinterpret_cast<const float4 *>(Sb + Cp + cc + 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const u32x4 w = *reinterpret_cast<const u32x4 *>(Ws + (size_t)t * Cp + cc);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    fma_mix_lo(d[2 * j], x[i][t][j], w[j]);
-                    fma_mix_hi(d[2 * j + 1], x[i][t][j], w[j]);
-                }
-            }
-            half8 h;
-            h[0] = (yk_half)yk_actf(d[0] * sc0.x + bs0.x, a.dw_slope, a.dw_cap);
-            h[1] = (yk_half)yk_actf(d[1] * sc0.y + bs0.y, a.dw_slope, a.dw_cap);
-            h[2] = (yk_half)yk_actf(d[2] * sc0.z + bs0.z, a.dw_slope, a.dw_cap);
-            h[3] = (yk_half)yk_actf(d[3] * sc0.w + bs0.w, a.dw_slope, a.dw_cap);
-            h[4] = (yk_half)yk_actf(d[4] * sc1.x + bs1.x, a.dw_slope, a.dw_cap);
-            h[5] = (yk_half)yk_actf(d[5] * sc1.y + bs1.y, a.dw_slope, a.dw_cap);
-            h[6] = (yk_half)yk_actf(d[6] * sc1.z + bs1.z, a.dw_slope, a.dw_cap);
-            h[7] = (yk_half)yk_actf(d[7] * sc1.w + bs1.w, a.dw_slope, a.dw_cap);
-            xf[i] = (cv && valid[i]) ? h : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    }
-
-    // epilogue: lane holds channels n..n+3 of pixel fr -> one 8-byte store per (pixel tile, channel tile)
-    yk_half *o = reinterpret_cast<yk_half *>(a.out);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = j * 16 + kg * 4;
-        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n);
-        const float4 bs = *reinterpret_cast<const float4 *>(a.bias + n);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = mb + i * 16 + fr;
-            half4 h = {(yk_half)yk_actf(acc[i][j][0] * sc.x + bs.x, a.slope, a.cap), (yk_half)yk_actf(acc[i][j][1] * sc.y + bs.y, a.slope, a.cap),
-                       (yk_half)yk_actf(acc[i][j][2] * sc.z + bs.z, a.slope, a.cap), (yk_half)yk_actf(acc[i][j][3] * sc.w + bs.w, a.slope, a.cap)};
-            if (m < a.M && n < a.outp) {
-                if (a.res && n < a.resp) {
-                    const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + n);
-                    h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
-                              (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
-                }
-                *reinterpret_cast<half4 *>(o + (size_t)m * a.outp + n) = h;
-            }
-        }
-    }
-}
-
-template <int TM, int TN>
-static int launch_wave(const igemm_args &a, hipStream_t st) {
-    const size_t lds = (size_t)9 * a.c0p * 2 + (size_t)2 * a.c0p * 4;
-    const int waves = (a.M + 16 * TM - 1) / (16 * TM);
-    hipLaunchKernelGGL((fused_wave_kernel<TM, TN>), dim3((waves + 3) / 4), dim3(256), lds, st, a);
-    return YK_OK;
-}
-
 template <int WM, int WN, int TM, int WPF>
 static int launch_wide(const igemm_args &a, hipStream_t st) {
     constexpr int BM = WM * 16 * TM, BN = WN * 16;
@@ -1966,22 +1683,15 @@ bool yk_igemm_fused_ok(int c0p, int cout) {
 int yk_igemm_fused_pick(const igemm_args &a) {
     const int G = a.c0p >> 3;
     // small-spatial blocks (<= 28x40 at batch 32): the LDS-DMA staged kernel (yk_fused_dma.h)
-    static const bool fdma_on = getenv("YK_FDMA") ? getenv("YK_FDMA")[0] != '0' : true;
+    static const bool fdma_on = yk_dev_env("YK_FDMA") ? yk_dev_env("YK_FDMA")[0] != '0' : true;
     if (fdma_on && a.c0p >= 96 && a.M <= 65536) {
         // measured against fused_wide at batch 32: 96->192 s2 21.3 -> 18.5 us, 384->384 17.7 -> 15.7, 384->768 s2 17.7 -> 14.4; the
         // 192->192 block (448 patches = two rounds of one 768-thread workgroup per CU) 18.1 -> 20.9: keeps the old kernel
         const fdma_plan pl = yk_fdma_plan(a);
         if (pl.npw && (pl.rounds == 1 || a.c0p <= 96)) return FUSED_DMA;
     }
-    static const bool wide = getenv("YK_WIDE") ? getenv("YK_WIDE")[0] != '0' : true;
-    static const int wavek = getenv("YK_WAVE") ? atoi(getenv("YK_WAVE")) : 0;   // 0 off, 1/2 = TM
-    if (wavek && a.c0p <= 192 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) {
-        const int tn = (a.N + 15) / 16;
-        if (tn <= 3) return wavek == 1 ? WAVE_T1_N3 : WAVE_T2_N3;
-        if (tn <= 6) return wavek == 1 ? WAVE_T1_N6 : WAVE_T2_N6;
-        return wavek == 1 ? WAVE_T1_N12 : WAVE_T2_N12;
-    }
-    static const bool lr = getenv("YK_LR") ? getenv("YK_LR")[0] != '0' : true;
+    static const bool wide = yk_dev_env("YK_WIDE") ? yk_dev_env("YK_WIDE")[0] != '0' : true;
+    static const bool lr = yk_dev_env("YK_LR") ? yk_dev_env("YK_LR")[0] != '0' : true;
     // (an LDS-DMA staged variant of this kernel was built and measured: 34.5 vs 33.0 us on the 24->48 block - these layers are bound by
     // VALU issue, ~650 vector instructions per wave of which 108 are the depthwise MACs, not by how the taps are fetched; dropped)
     if (lr && a.c0p <= 128 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) return (a.c0p <= 48) ? LR_T2 : LR_T1;
@@ -1994,18 +1704,10 @@ int yk_igemm_fused_pick(const igemm_args &a) {
         const int ns = (a.N + 191) / 192;
         const int tiles_m = 256 / ns > 0 ? 256 / ns : 1;
         const int tm = ((a.M + tiles_m - 1) / tiles_m + 15) / 16;
-        // 12-deep weight preload (48 VGPRs) helped one batch alone by a hair and costs co-residency: off (124 vs 121 k images/s in flight)
-        static const bool deep_on = getenv("YK_DEEP") ? getenv("YK_DEEP")[0] != '0' : false;
-        const bool deep = deep_on && a.c0p > 192;
-        if (!deep) {
-            if (tm <= 2) return WIDE_1x12_T2;
-            if (tm <= 4) return WIDE_1x12_T4;
-            if (tm <= 5) return WIDE_1x12_T5;
-            return WIDE_1x12_T9;
-        }
-        if (tm <= 2) return WIDE_1x12_T2_D12;
-        if (tm <= 3) return WIDE_1x12_T3_D12;
-        return WIDE_1x12_T5_D12;
+        if (tm <= 2) return WIDE_1x12_T2;
+        if (tm <= 4) return WIDE_1x12_T4;
+        if (tm <= 5) return WIDE_1x12_T5;
+        return WIDE_1x12_T9;
     }
     if (a.N <= 48) return FUSED_128x48;
     if (a.N <= 96) return FUSED_128x96;
@@ -2015,7 +1717,7 @@ int yk_igemm_fused_pick(const igemm_args &a) {
 }
 const char *yk_igemm_fused_name(int cfg) {
     static const char *n[] = {"fused_128x48", "fused_128x96", "fused_64x192", "fused_32x192", "wide_256x48", "wide_128x96",
-                              "wide_64x96", "wide_64x192", "wide_32x192", "wide_32x192d12", "lr_64", "lr_128", "wave16_n48", "wave32_n48", "wave16_n96", "wave32_n96", "wave16_n192", "wave32_n192", "wide_48x192d12", "wide_80x192d12", "wide_80x192", "wide_144x192", "fdma"};
+                              "wide_64x96", "wide_64x192", "wide_32x192", "lr_64", "lr_128", "wide_80x192", "wide_144x192", "fdma"};
     return (cfg >= 0 && cfg < FUSED_NUM) ? n[cfg] : "?";
 }
 int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st) {
@@ -2029,19 +1731,10 @@ int yk_launch_igemm_fused(int cfg, const igemm_args &a, hipStream_t st) {
     case WIDE_2x6_T2: return launch_wide<2, 6, 2, 6>(a, st);
     case WIDE_1x12_T4: return launch_wide<1, 12, 4, 6>(a, st);
     case WIDE_1x12_T2: return launch_wide<1, 12, 2, 6>(a, st);
-    case WIDE_1x12_T2_D12: return launch_wide<1, 12, 2, 12>(a, st);
-    case WIDE_1x12_T3_D12: return launch_wide<1, 12, 3, 12>(a, st);
-    case WIDE_1x12_T5_D12: return launch_wide<1, 12, 5, 12>(a, st);
     case WIDE_1x12_T5: return launch_wide<1, 12, 5, 6>(a, st);
     case WIDE_1x12_T9: return launch_wide<1, 12, 9, 6>(a, st);
     case LR_T1: return launch_lr<1>(a, st);
     case LR_T2: return launch_lr<2>(a, st);
-    case WAVE_T1_N3: return launch_wave<1, 3>(a, st);
-    case WAVE_T2_N3: return launch_wave<2, 3>(a, st);
-    case WAVE_T1_N6: return launch_wave<1, 6>(a, st);
-    case WAVE_T2_N6: return launch_wave<2, 6>(a, st);
-    case WAVE_T1_N12: return launch_wave<1, 12>(a, st);
-    case WAVE_T2_N12: return launch_wave<2, 12>(a, st);
     case FUSED_DMA: return yk_launch_fdma(a, st);
     }
     yk_set_error("yk_launch_igemm_fused: bad config %d", cfg);
