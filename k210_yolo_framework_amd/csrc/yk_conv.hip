@@ -843,7 +843,7 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     // small tile; short ones keep 128x64, whose per-workgroup fixed cost is amortised over more output.
     // with LDS-DMA tiles the 64x128x64 config is the fastest wherever it applies (52x52 128->256: 519 vs 460 TFLOP/s for 64x64x64,
     // 13x13 512->1024: 480 vs 447); the register-staged fallbacks (upsampled input, channel pitch not a multiple of 64) keep 64x64
-    const bool dma_ok = !a.up0 && ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);
+    const bool dma_ok = ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);     // upsampled sources included (yk_igemm_pipe.h)
     if (a.K >= 512) return (a.N % 128 == 0 && dma_ok) ? IGEMM_64x128 : IGEMM_64x64;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;
@@ -1524,7 +1524,7 @@ __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
 // 12*TM registers; depthwise weights come from LDS.
 // -------------------------------------------------------------------------------------
 template <int TM>
-__global__ void __launch_bounds__(256) fused_lr_kernel(const igemm_args a) {
+__global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     constexpr int NT = 256, BM = 64 * TM, TN = 3;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + a.lda_pad;

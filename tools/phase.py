@@ -26,7 +26,7 @@ v = out[out[:, 0] > 0]
 t0 = v[:, 0].min()
 print(name, 'workgroups', len(v), 'kernel span %.2f us' % ((v[:, 6].max() - t0) / 100.0))
 d = (v - v[:, :1]) / 100.0
-lab = ['start', 'issued', 'landed+bar', 'dw+bar', 'gemm+bar', 'C tile+bar', 'stored']
+lab = ['start', 'Ws+bar', 'dw done', 'barrier', 'gemm+C', 'barrier', 'stored']
 for k in range(1, 7):
     print('  %-12s median %6.2f us  p90 %6.2f  max %6.2f' % (lab[k], np.median(d[:, k]), np.percentile(d[:, k], 90), d[:, k].max()))
 st = (v[:, 0] - t0) / 100.0

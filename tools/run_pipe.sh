@@ -1,1 +1,2 @@
-for cfg in 4 5 9 10 3 8; do for sk in 2 4; do echo "cfg=$cfg split=$sk"; YK_IGEMM_FORCE=$cfg YK_FORCE_MINK=4000 YK_SPLIT_FORCE=$sk python tools/kbench.py 32 2>&1 | grep "768to192\|reduce.*192\|512to128\|reduce.*128+"; done; done
+python -m pytest tests/test_gpu_layers.py -x -q 2>&1 | grep -E "passed|failed"
+python tools/kbench.py 32 2>&1 | sed -n 2,24p
