@@ -87,32 +87,46 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
+    // Per-step address work is ONE add per DMA instruction: everything that depends on the filter tap (row validity, the tap's byte
+    // offset in either source, the upsampled coordinates) is folded into aoff0/aoff1 when the tap CHANGES, i.e. every Ctp/64 steps
+    // (counters of the previous version: 85 vector + 65 scalar instructions per 16 MFMAs, most of them this arithmetic).
     const int lim = kt0 + nk;
     int step = kt0;
     int tap = (int)yk_div((uint32_t)kt0 * BK, a.fd_ctp);
     int cin = kt0 * BK - tap * Ctp;
-    auto dma = [&](int stage) {
-        const bool src1 = cin >= a.c0p;
+    uint32_t aoff0[A_IT], aoff1[A_IT];
+    auto retap = [&]() {
         const int ky = (a.ks == 3) ? (tap * 11) >> 5 : 0, kx = tap - ky * a.ks;
-        const bool live = (step < lim) && (tap < taps);
-        const uint32_t toff = (uint32_t)((ky * a.Wi + kx) * (src1 ? a.c1p : a.c0p)) * 2u + (uint32_t)cin * 2u;
-        const uint32_t soff = live ? toff : YK_OOB;
-        const uint32_t cs = live ? (uint32_t)cin * 2u : YK_OOB;
-        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
-        yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+        const uint32_t t0 = (uint32_t)((ky * a.Wi + kx) * a.c0p) * 2u, t1 = (uint32_t)((ky * a.Wi + kx) * a.c1p) * 2u;
+        const bool tlive = tap < taps;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            uint32_t o;
-            if constexpr (UP) {
-                const uint32_t up = P0[it] + (uint32_t)((((ry[it] + ky) >> 1) * W0 + ((rx[it] + kx) >> 1)) * a.c0p) * 2u + cs;
-                o = src1 ? P1[it] + soff : up;
-            } else {
-                o = (src1 ? P1[it] : P0[it]) + soff;
+            const bool ok = tlive && ((rmask[it] >> tap) & 1u);
+            uint32_t o0;
+            if constexpr (UP) o0 = P0[it] + (uint32_t)((((ry[it] + ky) >> 1) * W0 + ((rx[it] + kx) >> 1)) * a.c0p) * 2u;
+            else o0 = P0[it] + t0;
+            aoff0[it] = ok ? o0 : YK_OOB;
+            aoff1[it] = ok ? P1[it] + t1 : YK_OOB;
+        }
+    };
+    retap();
+    auto dma = [&](int stage) {
+        const bool live = step < lim;
+        const uint32_t cs = live ? (uint32_t)cin * 2u : YK_OOB;                  // dead steps (past the split's end) deposit zeros
+        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
+        yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+        if (cin >= a.c0p) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const uint32_t off = aoff1[it] + cs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(As + (wid + it * NW) * 8 * BK), 16, off, 0, 0, 0);
             }
-            const uint32_t off = ((rmask[it] >> tap) & 1u) ? o : YK_OOB;
-            lds_ptr_t dst = (lds_ptr_t)(As + (wid + it * NW) * 8 * BK);
-            if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const uint32_t off = aoff0[it] + cs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(As + (wid + it * NW) * 8 * BK), 16, off, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -122,9 +136,11 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
         }
         ++step;
         cin += BK;
-        const bool wrap = cin >= Ctp;
-        cin = wrap ? 0 : cin;
-        tap += wrap ? 1 : 0;
+        if (cin >= Ctp) {                                                         // uniform, every Ctp/64 steps
+            cin = 0;
+            ++tap;
+            retap();
+        }
     };
     floatx4 acc[TM][TN];
 #pragma unroll
