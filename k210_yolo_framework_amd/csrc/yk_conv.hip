@@ -1531,13 +1531,32 @@ __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     const int npass = (a.N + 47) / 48, CS_LD = npass * 48 + 8;
     yk_half *As = reinterpret_cast<yk_half *>(yk_smem);
     yk_half *Ws = As + (size_t)BM * LDA;
-    yk_half *Cs = Ws + (size_t)9 * Cp;
+    const int nsl = (a.N + 15) >> 4;                                 // 16-channel slices of the pointwise weights
+    yk_half *Wp = Ws + (size_t)9 * Cp;                               // pointwise weights, MFMA fragment order [slice][k-step][lane][8]
+    float *Sb = reinterpret_cast<float *>(Wp + (size_t)nsl * (Kp >> 5) * 512);   // pointwise BatchNorm scale | bias, [2][npass*48]
+    yk_half *Cs = As;                                                // output tile: reuses the depthwise tile / weights after the GEMM
     const int m0 = yk_xcd_tile(blockIdx.x, gridDim.x) * BM;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     const int nk = Kp >> 5;
 
+    // the whole pointwise weight matrix (<= 18 KB) is requested into LDS by DMA before anything else: it lands under the depthwise
+    // phase.  (Phase stamps of the previous version: the GEMM phase was 1.8 us of a 5.4 us workgroup lifetime for SIX MFMAs - it
+    // opened with a round trip to L2 for the weight fragments.)
+    {
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+        const int w16 = nsl * nk * 64;
+        for (int q0 = wid * 64; q0 < w16; q0 += NT) {
+            const uint32_t offw = (uint32_t)(q0 + lane) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Wp + (size_t)q0 * 8), 16, offw, 0, 0, 0);
+        }
+    }
     for (int v = tid; v < 9 * (Cp >> 3); v += NT)
         *reinterpret_cast<half8 *>(Ws + v * 8) = *reinterpret_cast<const half8 *>(a.dw_w + (size_t)v * 8);
+    for (int v = tid; v < npass * 48; v += NT) {                     // arrays are zero-padded past N (yk_engine.hip upload_sb)
+        Sb[v] = a.scale[v];
+        Sb[npass * 48 + v] = a.bias[v];
+    }
     {
         const int padv = (Kp - Cp) >> 3;
         for (int v = tid; v < BM * padv; v += NT) {
@@ -1571,51 +1590,66 @@ __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     }
     __syncthreads();
 
-    // ---- phase B: N in passes of 48 columns; wave w owns rows [w*16*TM, (w+1)*16*TM)
+    // ---- phase B: N in passes of 48 columns; wave w owns rows [w*16*TM, (w+1)*16*TM).  The results of all passes stay in registers
+    // (packed fp16) until every wave is done reading the depthwise tile and the weights: the output tile then takes their place in
+    // LDS, which keeps the workgroup's footprint at max(inputs, outputs) instead of their sum - more workgroups per CU.
     const int nl4 = (lane >> 4) * 4;
     const bool capped_o = a.cap < 3.0e38f;
-    for (int ps = 0; ps < npass; ++ps) {
-        floatx4 acc[TM][TN];
+    half8 xf[TM][4];                                                 // c0p <= 128: at most four k-steps of 32
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            half8 wf[TN], xf[TM];
+        for (int kt = 0; kt < 4; ++kt)
+            xf[i][kt] = *reinterpret_cast<const half8 *>(As + ((wid * TM + i) * 16 + fr) * LDA + min(kt, nk - 1) * 32 + fk);
+    half4 outv[4][TM][TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ps * 48 + j * 16 + fr, k = kt * 32 + fk;
-                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (n < a.N && k < a.K) v = *reinterpret_cast<const half8 *>(a.w + (size_t)n * a.K + k);
-                wf[j] = v;
+    for (int ps = 0; ps < 4; ++ps) {
+        if (ps < npass) {
+            floatx4 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt < nk) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int sl = min(ps * TN + j, nsl - 1);    // slices past N: a valid address, the result is never stored
+                        const half8 wf = *reinterpret_cast<const half8 *>(Wp + (((size_t)sl * nk + kt) * 64 + lane) * 8);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[i][kt], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xf[i] = *reinterpret_cast<const half8 *>(As + ((wid * TM + i) * 16 + fr) * LDA + kt * 32 + fk);
+            for (int j = 0; j < TN; ++j) {
+                const int nl = ps * 48 + j * 16 + nl4;
+                const float4 sc = *reinterpret_cast<const float4 *>(Sb + nl);
+                const float4 bs = *reinterpret_cast<const float4 *>(Sb + npass * 48 + nl);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = ps * 48 + j * 16 + nl4;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + nl);
-            const float4 bs = *reinterpret_cast<const float4 *>(a.bias + nl);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int ml = (wid * TM + i) * 16 + fr, m = m0 + ml;
-                half4 h = capped_o ? epi4<true>(acc[i][j], sc, bs, a.slope, a.cap) : epi4<false>(acc[i][j], sc, bs, a.slope, a.cap);
-                if (a.res && m < a.M && nl < a.resp) {
-                    const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + nl);
-                    h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
-                              (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
+                for (int i = 0; i < TM; ++i) {
+                    const int ml = (wid * TM + i) * 16 + fr, m = m0 + ml;
+                    half4 h = capped_o ? epi4<true>(acc[i][j], sc, bs, a.slope, a.cap) : epi4<false>(acc[i][j], sc, bs, a.slope, a.cap);
+                    if (a.res && m < a.M && nl < a.resp) {
+                        const half4 rr = *reinterpret_cast<const half4 *>(a.res + (size_t)m * a.resp + nl);
+                        h = half4{(yk_half)((float)h[0] + (float)rr[0]), (yk_half)((float)h[1] + (float)rr[1]),
+                                  (yk_half)((float)h[2] + (float)rr[2]), (yk_half)((float)h[3] + (float)rr[3])};
+                    }
+                    outv[ps][i][j] = h;
                 }
-                *reinterpret_cast<half4 *>(Cs + ml * CS_LD + nl) = h;
             }
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+        if (ps < npass)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    *reinterpret_cast<half4 *>(Cs + ((wid * TM + i) * 16 + fr) * CS_LD + ps * 48 + j * 16 + nl4) = outv[ps][i][j];
     __syncthreads();
     const int VPR = a.outp >> 3;
     yk_half *o = reinterpret_cast<yk_half *>(a.out);
@@ -1630,7 +1664,8 @@ template <int TM>
 static int launch_lr(const igemm_args &a, hipStream_t st) {
     constexpr int BM = 64 * TM;
     const int Kp = (a.c0p + 31) & ~31, npass = (a.N + 47) / 48;
-    const size_t lds = ((size_t)BM * (Kp + a.lda_pad) + (size_t)9 * a.c0p + (size_t)BM * (npass * 48 + 8)) * 2;
+    const size_t lds_in = ((size_t)BM * (Kp + a.lda_pad) + (size_t)9 * a.c0p + (size_t)((a.N + 15) / 16) * (Kp / 32) * 512) * 2 + (size_t)2 * npass * 48 * 4;
+    const size_t lds = std::max(lds_in, (size_t)BM * (npass * 48 + 8) * 2);   // the output tile reuses the input side
     static size_t attr_lds = 64 * 1024;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_lr_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -448,9 +448,9 @@ extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops,
             g.M = max_batch * Y.h * Y.w;   // for config choice; patched per run
             l.cfg = dwo ? yk_igemm_fused_pick(g) : yk_igemm_pick(g, f32);
             l.out_f32 = f32;
-            if (dwo && l.cfg == FUSED_DMA) {
-                yk_fdma_fill(g);
-                // the LDS-DMA staged kernel reads its pointwise panel in MFMA fragment order: [16-channel slice][k-step of 32][lane][8],
+            if (dwo && (l.cfg == FUSED_DMA || l.cfg == LR_T1 || l.cfg == LR_T2)) {
+                if (l.cfg == FUSED_DMA) yk_fdma_fill(g);
+                // the LDS-DMA staged kernel and the LR kernels read their pointwise panel in MFMA fragment order: [16-channel slice][k-step of 32][lane][8],
                 // element = W[slice*16 + (lane & 15)][kstep*32 + (lane >> 4)*8 + e]; one wave-load = 1 KB contiguous
                 const int Kp = (c0p + 31) & ~31, nkf = Kp / 32, nsl = (co + 15) / 16;
                 std::vector<uint16_t> wf((size_t)nsl * nkf * 512, 0);
