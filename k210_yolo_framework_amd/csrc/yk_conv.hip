@@ -739,7 +739,11 @@ template <int BM, int BN, int WM, int WN, int BK, bool F32, bool UNI_OK = false>
 static int launch_cfg(const igemm_args &a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
     static const bool uni_on = yk_dev_env("YK_UNI") ? yk_dev_env("YK_UNI")[0] != '0' : true;
-    const bool uni = uni_on && UNI_OK && ((a.c0p + a.c1p) % BK == 0) && (a.c0p % BK == 0) && a.in0_bytes < YK_OOB && a.in1_bytes < YK_OOB;
+    // "dead" taps / rows are addressed at P + YK_OOB where P may be (mod 2^32) up to one image row + one pixel BELOW zero (the halo of the
+    // first output row): the whole tensor plus that margin must stay under YK_OOB for the sum to be out of the descriptor's range
+    const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
+    const bool uni = uni_on && UNI_OK && ((a.c0p + a.c1p) % BK == 0) && (a.c0p % BK == 0) && (uint64_t)a.in0_bytes + margin < YK_OOB &&
+                     (uint64_t)a.in1_bytes + margin < YK_OOB;
     constexpr size_t stages = (size_t)2 * (BM + BN) * (BK + YK_LDPAD) * 2, ctile = F32 ? 0 : (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stages > ctile ? stages : ctile;
     auto go = [&](auto kern) {

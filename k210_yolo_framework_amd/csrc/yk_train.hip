@@ -568,8 +568,12 @@ __global__ void __launch_bounds__(256) bn_stats_finish_kernel(const double *__re
         mean[c] = (float)mu;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (mm && mv) {                                  // keras: moving = moving*momentum + batch*(1-momentum)
+            // TF 1.14 takes the fused path for NHWC 4-D inputs (tf.nn.fused_batch_norm): normalisation uses the population variance,
+            // the MOVING variance is fed the Bessel-corrected one, var * M / (M - 1)
+            const double Mrows = 1.0 / invM;
+            const double uvar = Mrows > 1.5 ? var * Mrows / (Mrows - 1.0) : var;
             mm[c] = mm[c] * mom + (float)mu * (1.f - mom);
-            mv[c] = mv[c] * mom + (float)var * (1.f - mom);
+            mv[c] = mv[c] * mom + (float)uvar * (1.f - mom);
         }
     }
 }

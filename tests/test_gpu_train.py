@@ -321,9 +321,17 @@ def test_moving_statistics_follow_keras_momentum_rule():
     got_preds = tr.forward(_cu(x))
     for gp, rp in zip(got_preds, preds):
         _close(gp.cpu().numpy(), rp, 2e-4)
+    rows = {}
+    for op in spec.ops:                                                   # samples per channel of each BatchNorm: B * h * w
+        if op.get('layer'):
+            ho, wo, _ = spec.tensors[op['out']]
+            l = next(l for l in spec.layers if l.name == op['layer'])
+            if l.bn_name:
+                rows[l.bn_name] = 4 * ho * wo
     for bn, (mu, var) in stats.items():
         _close(tr.moving[bn + '/moving_mean'].cpu().numpy(), 0.99 * w[bn + '/moving_mean'] + 0.01 * mu, 1e-4)
-        _close(tr.moving[bn + '/moving_variance'].cpu().numpy(), 0.99 * w[bn + '/moving_variance'] + 0.01 * var, 1e-4)
+        m = rows[bn]                                                      # fused_batch_norm feeds the moving average the unbiased variance
+        _close(tr.moving[bn + '/moving_variance'].cpu().numpy(), 0.99 * w[bn + '/moving_variance'] + 0.01 * var * m / (m - 1), 1e-4)
 
 
 def test_training_step_is_bitwise_reproducible():
