@@ -164,7 +164,7 @@ int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, 
                         double *bytes_per_image);
 
 /* Per-launch timing: replays the plan `iters` times with HIP events recorded on `stream` around every
- * launch; ms_out[i] (i < yk_plan_launch_count) = average duration of launch i in milliseconds. */
+ * launch; ms_out[i] (i < yk_plan_launch_count) = median duration of launch i over the replays, in milliseconds. */
 int yk_plan_profile(yk_plan_t *p, const uint8_t *d_frames, int batch, int iters, void *stream, float *ms_out);
 
 /* ---- decode ---------------------------------------------------------------- */

@@ -639,7 +639,7 @@ static int run_plan(yk_plan *p, const void *d_in, int in_f32, int batch, void *s
 }
 
 // Per-launch timing with HIP events recorded on the SAME stream the kernels run on.
-// ms_out[i] = average duration of launch i over `iters` replays (i < yk_plan_launch_count).
+// ms_out[i] = median duration of launch i over `iters` replays (i < yk_plan_launch_count).
 extern "C" int yk_plan_profile(yk_plan_t *p, const uint8_t *d_frames, int batch, int iters, void *stream, float *ms_out) {
     if (!p || !ms_out || iters <= 0) {
         yk_set_error("yk_plan_profile: bad argument");
@@ -648,20 +648,25 @@ extern "C" int yk_plan_profile(yk_plan_t *p, const uint8_t *d_frames, int batch,
     const int n = yk_plan_launch_count(p);
     std::vector<hipEvent_t> ev(2 * n);
     for (auto &e : ev) YK_HIP(hipEventCreate(&e));
-    std::vector<double> acc(n, 0.0);
+    std::vector<std::vector<float>> samples(n);
     int rc = YK_OK;
-    for (int it = 0; it < iters && rc == YK_OK; ++it) {
+    for (int it = -3; it < iters && rc == YK_OK; ++it) {                  // three untimed replays first (clocks, caches, allocator)
         rc = run_plan(p, d_frames, 0, batch, stream, ev.data());
         if (rc) break;
         YK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (it < 0) continue;
         for (int i = 0; i < n; ++i) {
             float ms = 0.f;
             YK_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-            acc[i] += ms;
+            samples[i].push_back(ms);
         }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < n; ++i) ms_out[i] = (float)(acc[i] / iters);
+    for (int i = 0; i < n; ++i) {                                         // median over the replays: one slow replay (a clock dip, another
+        std::vector<float> &v = samples[i];                               // process' burst) must not define a launch's duration
+        std::sort(v.begin(), v.end());
+        ms_out[i] = v.empty() ? 0.f : (v.size() & 1 ? v[v.size() / 2] : 0.5f * (v[v.size() / 2 - 1] + v[v.size() / 2]));
+    }
     return rc;
 }
 
