@@ -135,7 +135,8 @@ def test_batchnorm_training_forward_backward(act, alpha, M, Cc):
     _close(sm.cpu().numpy(), mu.detach().numpy(), 1e-5)
     _close(si.cpu().numpy(), (1 / torch.sqrt(var + 1e-3)).detach().numpy(), 1e-5)
     _close(mm.cpu().numpy(), 0.01 * mu.detach().numpy(), 1e-5)
-    _close(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy(), 1e-5)
+    # the moving variance is fed the UNBIASED batch variance (tf fused_batch_norm; keras BatchNormalization fused=True)
+    _close(mv.cpu().numpy(), 0.99 + 0.01 * var.detach().numpy() * (M / (M - 1.0)), 1e-5)
     # activation kinks: an fp32 pre-activation within rounding of 0/6 may land on the other side — exclude those elements
     pre = ((zt - mu) / torch.sqrt(var + 1e-3) * gt + bt).detach().numpy()
     safe = (np.abs(pre) > 1e-4) & (np.abs(pre - 6) > 1e-4)
