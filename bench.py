@@ -49,6 +49,7 @@ def cpu_baseline(spec, weights, anchors, budget_s=10.0):
     rng = np.random.default_rng(0)
     B = 32
     cores = os.cpu_count() or 1
+    cores = oracle.set_threads(cores)          # the C port on every logical CPU (the tests run it on a 32-thread team)
     threads = torch.get_num_threads()
     res = {}
 

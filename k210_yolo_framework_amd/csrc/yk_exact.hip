@@ -33,11 +33,25 @@ __device__ __forceinline__ int x_exp_of(uint32_t amax_bits) {
 }
 __device__ __forceinline__ float x_pow2(int e) { return __uint_as_float((uint32_t)(127 + max(-126, min(127, e))) << 23); }
 
+// Per-image running maxima live in XS = 64 sub-slots per image: thousands of workgroups hitting ONE address with a device-scope atomic
+// serialise at ~0.25 us each across the XCDs (measured: 3/4 of every kernel's time, and a load-then-compare guard is worse still as
+// the load has to bypass L2).  A workgroup fires one no-return atomic at slot blockIdx.x % 64; a reader wave loads the 64 slots of an
+// image with one coalesced access and reduces them with cross-lane shuffles.
+constexpr int XS = 64;
+__device__ __forceinline__ void x_amax_global(uint32_t *img_slots, uint32_t bits) { atomicMax(img_slots + (blockIdx.x & (XS - 1)), bits); }
+// whole wave: max of image b's slots (every lane returns it)
+__device__ __forceinline__ uint32_t x_amax_wave(const uint32_t *base, int b) {
+    uint32_t v = base[(size_t)b * XS + (threadIdx.x & 63)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
 struct xconv_args {
     const float *in0, *in1;
     int c0p, c1p, up0;
     int Hi, Wi, Ho, Wo, ks, stride, pad_t, pad_l;
-    int M, N, K, HoWo;
+    int B, M, N, K, HoWo;
     const yk_half *w_hi, *w_lo;        // [N][K], w * 2^s split
     const float *scale, *bias;         // [N padded with zeros]; scale already carries 2^-s
     float slope, cap;
@@ -48,72 +62,188 @@ struct xconv_args {
     const uint32_t *amax_in0, *amax_in1;   // [max_batch] float bits of the per-image max |x| of the sources
     uint32_t *amax_out;                // [max_batch] or null
     yk_fastdiv fd_hw, fd_wo;
+    // pixel tiling: a workgroup's 64 GEMM rows are 64 >> sp_sh consecutive SR x SC patches (SR, SC powers of two; 1 x 1 = flat order)
+    int sr_sh, sc_sh, TX, TXY;
+    yk_fastdiv fd_txy, fd_tx;
+    // fused DepthwiseConv2D(3x3)+BN+act producing the GEMM's pixel operand (the 1x1 conv that follows it): in0 is the depthwise INPUT
+    const float *dw_par;               // [11][c0p] fp32: nine taps, scale, bias
+    int dw_Hi, dw_Wi, dw_stride, dw_pad_t, dw_pad_l;
+    float dw_slope, dw_cap, dw_gain, dw_off;   // |dw output| <= min(dw_cap, dw_gain * amax(in) + dw_off)
+    // split-K: partial accumulators go to slab[z][tile][reg][thread]; the last workgroup of a tile to arrive adds them in z order
+    int splitk, phase;                 // phase 0: whole K; 1: this z's share -> slab; 2: sum the slabs + epilogue
+    float *slab;
 };
 
-constexpr int XBM = 64, XBN = 64, XBK = 32, XLD = XBK + 16;
+constexpr int XBM = 64, XBK = 32, XLD = XBK + 16;
 
-// Conv2D 1x1 / 3x3 as an implicit GEMM with compensated fp16 operands.  256 threads = 2x2 waves, each a 32x32 output block.
+// operand exponent of image b, computed by a whole wave
+__device__ __forceinline__ int x_img_exp(const xconv_args &a, int b, bool dw) {
+    const uint32_t m0 = x_amax_wave(a.amax_in0, b);
+    if (dw) return x_exp_of(__float_as_uint(fminf(a.dw_cap, a.dw_gain * __uint_as_float(m0) + a.dw_off)));
+    int e = x_exp_of(m0);
+    if (a.in1) e = max(e, x_exp_of(x_amax_wave(a.amax_in1, b)));
+    return e;
+}
+
+// wave-wide max into an LDS slot: one atomic per wave when every lane targets the same slot (the common case: one image per tile)
+__device__ __forceinline__ void x_amax_lds(uint32_t *simg, int slot, float v) {
+    const int s0 = __builtin_amdgcn_readfirstlane(slot);
+    if (__all(slot == s0)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(&simg[s0], __float_as_uint(v));
+    } else if (v > 0.f) {
+        atomicMax(&simg[slot], __float_as_uint(v));
+    }
+}
+
+// Conv2D 1x1 / 3x3 as an implicit GEMM with compensated fp16 operands; with DW the pixel operand is produced on the fly by a
+// depthwise 3x3 + BN + activation in fp32 (never written to HBM).  256 threads = 2x2 waves, each a 32 x BN/2 output block.
+template <int BN, bool DW>
 __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
-    __shared__ __attribute__((aligned(16))) yk_half lds[2 * 4 * 64 * XLD];      // 2 stages x {A_hi, A_lo, B_hi, B_lo}
-    __shared__ uint32_t simg[XBM];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    constexpr int STG = (2 * XBM + 2 * BN) * XLD;                  // halfs per stage: A_hi, A_lo [64][XLD], B_hi, B_lo [BN][XLD]
+    constexpr int NB = BN / 64, NT = BN / 32;
+    yk_half *lds = reinterpret_cast<yk_half *>(xsm);
+    int *spix = reinterpret_cast<int *>(xsm + (size_t)2 * STG * 2);  // [64] output pixel index of each GEMM row (-1: none)
+    int *sb = spix + XBM;                                          // [64] its image
+    uint32_t *simg = reinterpret_cast<uint32_t *>(sb + XBM);       // [64] per-image max of this tile's outputs
+    int *sexp = reinterpret_cast<int *>(simg + XBM);               // [64] operand exponent of image sb[0] + i
+    float *dwl = reinterpret_cast<float *>(sexp + XBM);            // [11][c0p] depthwise parameters (DW)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.x * XBM, n0 = blockIdx.y * XBN;
+    const int n0 = blockIdx.y * BN;
     const int row = tid >> 2, kc = tid & 3;
     const int Ctp = a.c0p + a.c1p, taps = a.ks * a.ks;
     const int H0 = a.up0 ? (a.Hi >> 1) : a.Hi, W0 = a.up0 ? (a.Wi >> 1) : a.Wi;
-    if (tid < XBM) simg[tid] = 0u;
+    if (tid < XBM) {
+        const int sp_sh = a.sr_sh + a.sc_sh;
+        const uint32_t st = blockIdx.x * (XBM >> sp_sh) + (tid >> sp_sh), q = tid & ((1 << sp_sh) - 1);
+        const uint32_t b = x_div(st, a.fd_txy), rem = st - b * a.TXY;
+        const uint32_t ty = x_div(rem, a.fd_tx), tx = rem - ty * a.TX;
+        const int oy = (int)(ty << a.sr_sh) + (int)(q >> a.sc_sh), ox = (int)(tx << a.sc_sh) + (int)(q & ((1 << a.sc_sh) - 1));
+        const bool ok = (int)b < a.B && oy < a.Ho && ox < a.Wo;
+        spix[tid] = ok ? ((int)b * a.Ho + oy) * a.Wo + ox : -1;
+        sb[tid] = min((int)b, a.B - 1);
+        simg[tid] = 0u;
+    }
+    if (DW)
+        for (int i = tid; i < 11 * a.c0p / 4; i += 256) reinterpret_cast<float4 *>(dwl)[i] = reinterpret_cast<const float4 *>(a.dw_par)[i];
+    __syncthreads();
+    if (wid == 0) {                                                // operand exponent of every image this tile touches (usually one)
+        const int bl = sb[XBM - 1];
+        for (int b = sb[0]; b <= bl; ++b) {
+            const int e = x_img_exp(a, b, DW);
+            if (lane == 0) sexp[b - sb[0]] = e;
+        }
+    }
+    __syncthreads();
 
     // this thread's A row (one output pixel) and its operand scale
-    const int m = m0 + row;
-    const bool mok = m < a.M;
-    int rb = 0, riy = -(1 << 28), rix = 0;
+    const int m = spix[row];
+    const bool mok = m >= 0;
+    const int rb = sb[row], b0 = sb[0];
+    int riy = -(1 << 28), rix = 0;
     float sdown = 1.f;
+    unsigned vmask = 0;                                            // DW: which of the nine taps fall inside the image
+    const float *dwbase = a.in0;
     if (mok) {
-        const uint32_t b = x_div(m, a.fd_hw), rem = m - b * a.HoWo;
+        const uint32_t rem = m - rb * a.HoWo;
         const uint32_t oy = x_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
-        rb = b;
-        riy = (int)oy * a.stride - a.pad_t;
-        rix = (int)ox * a.stride - a.pad_l;
-        int e = x_exp_of(a.amax_in0[b]);
-        if (a.in1) e = max(e, x_exp_of(a.amax_in1[b]));
-        sdown = x_pow2(-e);
+        sdown = x_pow2(-sexp[rb - b0]);
+        if (DW) {
+            const int y0 = (int)oy * a.dw_stride - a.dw_pad_t, x0 = (int)ox * a.dw_stride - a.dw_pad_l;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(y0 + t / 3) < (unsigned)a.dw_Hi && (unsigned)(x0 + t % 3) < (unsigned)a.dw_Wi) vmask |= 1u << t;
+            dwbase = a.in0 + ((long long)(rb * a.dw_Hi + y0) * a.dw_Wi + x0) * a.c0p;
+        } else {
+            riy = (int)oy * a.stride - a.pad_t;
+            rix = (int)ox * a.stride - a.pad_l;
+        }
     }
-    const int nrow = n0 + row;
-    int kch = kc * 8, ktap = 0;
+    const int nk = (a.K + XBK - 1) / XBK;
+    const int per = (nk + a.splitk - 1) / a.splitk;
+    const int kb = blockIdx.z * per, ke = a.phase == 2 ? kb : min(nk, kb + per);
+    int kch = kb * XBK + kc * 8, ktap = 0;
     float4 ra0, ra1;
-    half8 rbh, rbl;
+    float4 xin[DW ? 9 : 1][2];
+    int dwch = 0;
+    half8 rbh[NB], rbl[NB];
     auto gload = [&](int k0) {
-        while (kch >= Ctp) {
-            kch -= Ctp;
-            ++ktap;
-        }
-        const int ky = (a.ks == 3) ? ktap / 3 : 0, kx = ktap - ky * a.ks;
-        const int iy = riy + ky, ix = rix + kx;
-        ra0 = ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ktap < taps && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
-            const float *p;
-            if (kch < a.c0p) {
-                const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
-                p = a.in0 + ((size_t)(rb * H0 + sy) * W0 + sx) * a.c0p + kch;
-            } else {
-                p = a.in1 + ((size_t)(rb * a.Hi + iy) * a.Wi + ix) * a.c1p + (kch - a.c0p);
+        if (DW) {
+            dwch = k0 + kc * 8;
+            const bool cok = dwch < a.c0p;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                xin[t][0] = xin[t][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cok && ((vmask >> t) & 1u)) {
+                    const float *p = dwbase + ((t / 3) * a.dw_Wi + (t % 3)) * a.c0p + dwch;
+                    xin[t][0] = *reinterpret_cast<const float4 *>(p);
+                    xin[t][1] = *reinterpret_cast<const float4 *>(p + 4);
+                }
             }
-            ra0 = *reinterpret_cast<const float4 *>(p);
-            ra1 = *reinterpret_cast<const float4 *>(p + 4);
+        } else {
+            while (kch >= Ctp) {
+                kch -= Ctp;
+                ++ktap;
+            }
+            const int ky = (a.ks == 3) ? ktap / 3 : 0, kx = ktap - ky * a.ks;
+            const int iy = riy + ky, ix = rix + kx;
+            ra0 = ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ktap < taps && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
+                const float *p;
+                if (kch < a.c0p) {
+                    const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
+                    p = a.in0 + ((size_t)(rb * H0 + sy) * W0 + sx) * a.c0p + kch;
+                } else {
+                    p = a.in1 + ((size_t)(rb * a.Hi + iy) * a.Wi + ix) * a.c1p + (kch - a.c0p);
+                }
+                ra0 = *reinterpret_cast<const float4 *>(p);
+                ra1 = *reinterpret_cast<const float4 *>(p + 4);
+            }
+            kch += XBK;
         }
-        rbh = rbl = half8{0, 0, 0, 0, 0, 0, 0, 0};
         const int k = k0 + kc * 8;
-        if (nrow < a.N && k < a.K) {
-            rbh = *reinterpret_cast<const half8 *>(a.w_hi + (size_t)nrow * a.K + k);
-            rbl = *reinterpret_cast<const half8 *>(a.w_lo + (size_t)nrow * a.K + k);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int nrow = n0 + row + 64 * i;
+            rbh[i] = rbl[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (nrow < a.N && k < a.K) {
+                rbh[i] = *reinterpret_cast<const half8 *>(a.w_hi + (size_t)nrow * a.K + k);
+                rbl[i] = *reinterpret_cast<const half8 *>(a.w_lo + (size_t)nrow * a.K + k);
+            }
         }
-        kch += XBK;
     };
     auto sstore = [&](int stage) {
-        yk_half *S = lds + stage * (4 * 64 * XLD);
-        const float v[8] = {ra0.x * sdown, ra0.y * sdown, ra0.z * sdown, ra0.w * sdown,
-                            ra1.x * sdown, ra1.y * sdown, ra1.z * sdown, ra1.w * sdown};
+        yk_half *S = lds + stage * STG;
+        float v[8];
+        if (DW) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (dwch < a.c0p) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(dwl + t * a.c0p + dwch);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(dwl + t * a.c0p + dwch + 4);
+                    acc[0] = fmaf(xin[t][0].x, w0.x, acc[0]);
+                    acc[1] = fmaf(xin[t][0].y, w0.y, acc[1]);
+                    acc[2] = fmaf(xin[t][0].z, w0.z, acc[2]);
+                    acc[3] = fmaf(xin[t][0].w, w0.w, acc[3]);
+                    acc[4] = fmaf(xin[t][1].x, w1.x, acc[4]);
+                    acc[5] = fmaf(xin[t][1].y, w1.y, acc[5]);
+                    acc[6] = fmaf(xin[t][1].z, w1.z, acc[6]);
+                    acc[7] = fmaf(xin[t][1].w, w1.w, acc[7]);
+                }
+                const float *sc = dwl + 9 * a.c0p + dwch, *bs = dwl + 10 * a.c0p + dwch;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = mok ? x_actf(acc[j] * sc[j] + bs[j], a.dw_slope, a.dw_cap) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[j] * sdown;
+        } else {
+            v[0] = ra0.x * sdown; v[1] = ra0.y * sdown; v[2] = ra0.z * sdown; v[3] = ra0.w * sdown;
+            v[4] = ra1.x * sdown; v[5] = ra1.y * sdown; v[6] = ra1.z * sdown; v[7] = ra1.w * sdown;
+        }
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -121,90 +251,115 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
             lo[j] = (yk_half)(v[j] - (float)hi[j]);
         }
         *reinterpret_cast<half8 *>(S + row * XLD + kc * 8) = hi;
-        *reinterpret_cast<half8 *>(S + 64 * XLD + row * XLD + kc * 8) = lo;
-        *reinterpret_cast<half8 *>(S + 2 * 64 * XLD + row * XLD + kc * 8) = rbh;
-        *reinterpret_cast<half8 *>(S + 3 * 64 * XLD + row * XLD + kc * 8) = rbl;
+        *reinterpret_cast<half8 *>(S + XBM * XLD + row * XLD + kc * 8) = lo;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            *reinterpret_cast<half8 *>(S + 2 * XBM * XLD + (row + 64 * i) * XLD + kc * 8) = rbh[i];
+            *reinterpret_cast<half8 *>(S + (2 * XBM + BN) * XLD + (row + 64 * i) * XLD + kc * 8) = rbl[i];
+        }
     };
-    floatx4 acc[2][2];
+    floatx4 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    const int nk = (a.K + XBK - 1) / XBK;
-    gload(0);
-    sstore(0);
+    if (kb < ke) {
+        gload(kb * XBK);
+        sstore(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * XBK);
-        const yk_half *S = lds + (kt & 1) * (4 * 64 * XLD);
-        half8 xh[2], xl[2], wh[2], wl[2];
+    for (int kt = kb; kt < ke; ++kt) {
+        if (kt + 1 < ke) gload((kt + 1) * XBK);
+        const yk_half *S = lds + ((kt - kb) & 1) * STG;
+        half8 xh[2], xl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             xh[i] = *reinterpret_cast<const half8 *>(S + ((wm * 2 + i) * 16 + fr) * XLD + fk);
-            xl[i] = *reinterpret_cast<const half8 *>(S + 64 * XLD + ((wm * 2 + i) * 16 + fr) * XLD + fk);
-            wh[i] = *reinterpret_cast<const half8 *>(S + 2 * 64 * XLD + ((wn * 2 + i) * 16 + fr) * XLD + fk);
-            wl[i] = *reinterpret_cast<const half8 *>(S + 3 * 64 * XLD + ((wn * 2 + i) * 16 + fr) * XLD + fk);
+            xl[i] = *reinterpret_cast<const half8 *>(S + XBM * XLD + ((wm * 2 + i) * 16 + fr) * XLD + fk);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const half8 wh = *reinterpret_cast<const half8 *>(S + 2 * XBM * XLD + (wn * (BN / 2) + j * 16 + fr) * XLD + fk);
+            const half8 wl = *reinterpret_cast<const half8 *>(S + (2 * XBM + BN) * XLD + (wn * (BN / 2) + j * 16 + fr) * XLD + fk);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
             }
-        if (kt + 1 < nk) sstore((kt + 1) & 1);
+        }
+        if (kt + 1 < ke) sstore(((kt - kb) + 1) & 1);
         __syncthreads();
     }
-    // epilogue: lane holds channels n..n+3 of pixel (wm*2+i)*16 + fr
+    if (a.splitk > 1) {
+        // phase 1: partial sums -> slab[z][tile][reg][thread]; phase 2 (a second launch of this kernel, grid.z = 1, no k loop): add the
+        // slabs in z order and finish.  (A "last workgroup reduces" scheme needs a device-scope release per workgroup, which on this
+        // multi-XCD part writes back the whole L2 each time: measured slower than the second launch.)
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, ntile = (size_t)gridDim.x * gridDim.y;
+        if (a.phase == 1) {
+            floatx4 *mine = reinterpret_cast<floatx4 *>(a.slab) + ((size_t)blockIdx.z * ntile + tile) * (2 * NT) * 256 + tid;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mine[(i * NT + j) * 256] = acc[i][j];
+            return;
+        }
+        for (int z = 0; z < a.splitk; ++z) {
+            const floatx4 *src = reinterpret_cast<const floatx4 *>(a.slab) + ((size_t)z * ntile + tile) * (2 * NT) * 256 + tid;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] += __builtin_nontemporal_load(src + (i * NT + j) * 256);
+        }
+    }
+    // epilogue: lane holds channels n..n+3 of GEMM row (wm*2+i)*16 + fr
     const int nl4 = (lane >> 4) * 4;
-    const uint32_t b0 = x_div(min(m0, a.M - 1), a.fd_hw);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int mm = m0 + (wm * 2 + i) * 16 + fr;
-        if (mm >= a.M) continue;
-        const uint32_t b = x_div(mm, a.fd_hw);
-        int e = x_exp_of(a.amax_in0[b]);
-        if (a.in1) e = max(e, x_exp_of(a.amax_in1[b]));
-        const float up = x_pow2(e);
+        const int r = (wm * 2 + i) * 16 + fr;
+        const int mm = spix[r], b = sb[r];
         float rmax = 0.f;
+        if (mm >= 0) {
+            const float up = x_pow2(sexp[b - b0]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + (wn * 2 + j) * 16 + nl4;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n), bs = *reinterpret_cast<const float4 *>(a.bias + n);
-            float4 v;
-            v.x = x_actf(acc[i][j][0] * up * sc.x + bs.x, a.slope, a.cap);
-            v.y = x_actf(acc[i][j][1] * up * sc.y + bs.y, a.slope, a.cap);
-            v.z = x_actf(acc[i][j][2] * up * sc.z + bs.z, a.slope, a.cap);
-            v.w = x_actf(acc[i][j][3] * up * sc.w + bs.w, a.slope, a.cap);
-            if (a.out_exact) {
-                float *o = a.out + (size_t)mm * a.outp + n;
-                if (n + 0 < a.N) o[0] = v.x;
-                if (n + 1 < a.N) o[1] = v.y;
-                if (n + 2 < a.N) o[2] = v.z;
-                if (n + 3 < a.N) o[3] = v.w;
-            } else if (n < a.outp) {
-                if (a.res && n < a.resp) {
-                    const float4 r = *reinterpret_cast<const float4 *>(a.res + (size_t)mm * a.resp + n);
-                    v.x += r.x;
-                    v.y += r.y;
-                    v.z += r.z;
-                    v.w += r.w;
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + nl4;
+                if (n >= (a.out_exact ? a.N : a.outp)) continue;
+                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + n), bs = *reinterpret_cast<const float4 *>(a.bias + n);
+                float4 v;
+                v.x = x_actf(acc[i][j][0] * up * sc.x + bs.x, a.slope, a.cap);
+                v.y = x_actf(acc[i][j][1] * up * sc.y + bs.y, a.slope, a.cap);
+                v.z = x_actf(acc[i][j][2] * up * sc.z + bs.z, a.slope, a.cap);
+                v.w = x_actf(acc[i][j][3] * up * sc.w + bs.w, a.slope, a.cap);
+                if (a.out_exact) {
+                    float *o = a.out + (size_t)mm * a.outp + n;
+                    if (n + 0 < a.N) o[0] = v.x;
+                    if (n + 1 < a.N) o[1] = v.y;
+                    if (n + 2 < a.N) o[2] = v.z;
+                    if (n + 3 < a.N) o[3] = v.w;
+                } else {
+                    if (a.res && n < a.resp) {
+                        const float4 q = *reinterpret_cast<const float4 *>(a.res + (size_t)mm * a.resp + n);
+                        v.x += q.x;
+                        v.y += q.y;
+                        v.z += q.z;
+                        v.w += q.w;
+                    }
+                    *reinterpret_cast<float4 *>(a.out + (size_t)mm * a.outp + n) = v;
+                    rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 }
-                *reinterpret_cast<float4 *>(a.out + (size_t)mm * a.outp + n) = v;
-                rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             }
         }
-        if (a.amax_out) atomicMax(&simg[b - b0], __float_as_uint(rmax));
+        if (a.amax_out) x_amax_lds(simg, b - b0, rmax);
     }
     if (a.amax_out) {
         __syncthreads();
-        if (tid < XBM && simg[tid]) atomicMax(a.amax_out + b0 + tid, simg[tid]);
+        if (tid < XBM && simg[tid] && b0 + tid < a.B) x_amax_global(a.amax_out + (size_t)(b0 + tid) * XS, simg[tid]);
     }
 }
 
-// ---- depthwise 3x3, fp32, one thread = (pixel, 4 channels) -------------------------------------------------
+// ---- depthwise 3x3, fp32, one thread = (pixel, 4 channels); grid (pixel groups of one image, image) ------------
 struct xdw_args {
     const float *in;
     int B, Hi, Wi, Ho, Wo, Cp, stride, pad_t, pad_l;
@@ -213,33 +368,30 @@ struct xdw_args {
     float slope, cap;
     float *out;
     uint32_t *amax_out;
+    yk_fastdiv fd_g, fd_wo;            // division by Cp/4 and Wo
 };
 __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
-    __shared__ uint32_t simg[256];
-    const int tid = threadIdx.x;
-    simg[tid] = 0u;
+    __shared__ uint32_t smax;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid == 0) smax = 0u;
     __syncthreads();
-    const int G = a.Cp >> 2;
-    const size_t total = (size_t)a.B * a.Ho * a.Wo * G;
-    const size_t first = (size_t)blockIdx.x * 256;
-    const int b0 = (int)((first / G) / ((size_t)a.Ho * a.Wo));
-    const size_t idx = first + tid;
-    if (idx < total) {
-        const int g = (int)(idx % G);
-        const size_t pix = idx / G;
-        const int ox = (int)(pix % a.Wo), oy = (int)((pix / a.Wo) % a.Ho), b = (int)(pix / ((size_t)a.Wo * a.Ho));
+    const uint32_t G = a.Cp >> 2, idx = blockIdx.x * 256 + tid;
+    float mx = 0.f;
+    if (idx < (uint32_t)(a.Ho * a.Wo) * G) {
+        const uint32_t pix = x_div(idx, a.fd_g), g = idx - pix * G;
+        const uint32_t oy = x_div(pix, a.fd_wo), ox = pix - oy * a.Wo;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int iy0 = oy * a.stride - a.pad_t, ix0 = ox * a.stride - a.pad_l;
+        const int iy0 = (int)oy * a.stride - a.pad_t, ix0 = (int)ox * a.stride - a.pad_l;
+        const float *src = a.in + (size_t)b * a.Hi * a.Wi * a.Cp + g * 4;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = iy0 + ky;
-            if ((unsigned)iy >= (unsigned)a.Hi) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ix0 + kx;
-                if ((unsigned)ix >= (unsigned)a.Wi) continue;
-                const float4 x = *reinterpret_cast<const float4 *>(a.in + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * a.Cp + g * 4);
-                const float4 w = *reinterpret_cast<const float4 *>(a.w + (size_t)(ky * 3 + kx) * a.Cp + g * 4);
+                const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                const float4 x = ok ? *reinterpret_cast<const float4 *>(src + (iy * a.Wi + ix) * a.Cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 w = *reinterpret_cast<const float4 *>(a.w + (ky * 3 + kx) * a.Cp + g * 4);
                 acc.x = fmaf(x.x, w.x, acc.x);
                 acc.y = fmaf(x.y, w.y, acc.y);
                 acc.z = fmaf(x.z, w.z, acc.z);
@@ -252,12 +404,13 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
         v.y = x_actf(acc.y * sc.y + bs.y, a.slope, a.cap);
         v.z = x_actf(acc.z * sc.z + bs.z, a.slope, a.cap);
         v.w = x_actf(acc.w * sc.w + bs.w, a.slope, a.cap);
-        *reinterpret_cast<float4 *>(a.out + pix * a.Cp + g * 4) = v;
-        const float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        atomicMax(&simg[min(b - b0, 255)], __float_as_uint(mx));
+        *reinterpret_cast<float4 *>(a.out + ((size_t)b * a.Ho * a.Wo + pix) * a.Cp + g * 4) = v;
+        mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    if (!a.amax_out) return;
+    x_amax_lds(&smax, 0, mx);
     __syncthreads();
-    if (simg[tid] && b0 + tid < a.B) atomicMax(a.amax_out + b0 + tid, simg[tid]);
+    if (tid == 0 && smax) x_amax_global(a.amax_out + (size_t)b * XS, smax);
 }
 
 // ---- stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once
@@ -273,16 +426,12 @@ struct xstem_args {
 };
 template <int COUT>
 __global__ void __launch_bounds__(256) xstem_kernel(const xstem_args a) {
-    __shared__ __attribute__((aligned(16))) float wl[27 * COUT];
-    __shared__ float sc[COUT], bs[COUT];
+    // the 27 x COUT weights, scale and bias are the same for every lane: read straight from the kernel-argument pointers they become
+    // scalar loads feeding v_fma's SGPR operand (through LDS every FMA paid a ds_read)
     __shared__ float lut[256];
     __shared__ uint32_t smax;
     const int tid = threadIdx.x, b = blockIdx.y;
-    for (int i = tid; i < 27 * COUT; i += 256) wl[i] = a.w[i];
-    if (tid < COUT) {
-        sc[tid] = a.scale[tid];
-        bs[tid] = a.bias[tid];
-    }
+    const float *__restrict__ wl = a.w, *__restrict__ sc = a.scale, *__restrict__ bs = a.bias;
     if (tid == 0) smax = 0u;
     if (!a.in_f32) {
         unsigned mx = 0;
@@ -344,7 +493,7 @@ __global__ void __launch_bounds__(256) xstem_kernel(const xstem_args a) {
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if ((tid & 63) == 0) atomicMax(&smax, __float_as_uint(vmax));
     __syncthreads();
-    if (tid == 0 && smax) atomicMax(a.amax_out + b, smax);
+    if (tid == 0 && smax) x_amax_global(a.amax_out + (size_t)b * XS, smax);
 }
 
 // ---- 2x2 max pool 'same' and residual add, fp32 ---------------------------------------------------------------
@@ -362,6 +511,8 @@ __global__ void __launch_bounds__(256) xpool_kernel(const xpool_args a) {
     const int G = a.Cp >> 2;
     const size_t total = (size_t)a.B * a.Ho * a.Wo * G, first = (size_t)blockIdx.x * 256, idx = first + tid;
     const int b0 = (int)((first / G) / ((size_t)a.Ho * a.Wo));
+    float mx = 0.f;
+    int slot = 0;
     if (idx < total) {
         const int g = (int)(idx % G);
         const size_t pix = idx / G;
@@ -380,11 +531,12 @@ __global__ void __launch_bounds__(256) xpool_kernel(const xpool_args a) {
                 m.w = fmaxf(m.w, x.w);
             }
         *reinterpret_cast<float4 *>(a.out + pix * a.Cp + g * 4) = m;
-        const float mx = fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
-        atomicMax(&simg[min(b - b0, 255)], __float_as_uint(mx));
+        mx = fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
+        slot = min(b - b0, 255);
     }
+    x_amax_lds(simg, slot, mx);
     __syncthreads();
-    if (simg[tid] && b0 + tid < a.B) atomicMax(a.amax_out + b0 + tid, simg[tid]);
+    if (simg[tid] && b0 + tid < a.B) x_amax_global(a.amax_out + (size_t)(b0 + tid) * XS, simg[tid]);
 }
 __global__ void __launch_bounds__(256) xadd_kernel(const float *x, const float *y, float *o, size_t n4_per_image, int B, uint32_t *amax_out) {
     __shared__ uint32_t smax;
@@ -404,7 +556,7 @@ __global__ void __launch_bounds__(256) xadd_kernel(const float *x, const float *
     for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&smax, __float_as_uint(mx));
     __syncthreads();
-    if (threadIdx.x == 0 && smax) atomicMax(amax_out + b, smax);
+    if (threadIdx.x == 0 && smax) x_amax_global(amax_out + (size_t)b * XS, smax);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -439,9 +591,43 @@ struct xlaunch {
     uint32_t *add_amax = nullptr;
     size_t add_n4 = 0;
     int Ho = 0, Wo = 0;
+    int bn = 64, dw = 0;               // xconv_kernel<bn, dw>
+    unsigned lds = 0;
     std::string name;
     double flops = 0, bytes = 0;
 };
+
+
+// pixel patch of a GEMM row tile: minimise (pixels computed / pixels kept) x (input halo read / patch); 1 x 1 = flat pixel order
+static void x_pick_patch(int Ho, int Wo, bool spatial, int *sr_sh, int *sc_sh) {
+    *sr_sh = *sc_sh = 0;
+    if (!spatial) return;
+    const double rows = 64.0 / Wo;
+    double best = Wo >= 64 ? 3.0 : (rows + 2.0) / rows;             // flat: 64 consecutive pixels touch their rows plus one above, one below
+    static const int cand[][2] = {{3, 3}, {2, 4}, {4, 2}, {2, 3}, {3, 2}};
+    for (auto &c : cand) {
+        const int SR = 1 << c[0], SC = 1 << c[1];
+        const double padded = (double)((Ho + SR - 1) / SR * SR) * ((Wo + SC - 1) / SC * SC) / ((double)Ho * Wo);
+        const double cost = padded * (SR + 2.0) * (SC + 2.0) / (SR * SC);
+        if (cost < best - 1e-9) {
+            best = cost;
+            *sr_sh = c[0];
+            *sc_sh = c[1];
+        }
+    }
+}
+static int x_pick_bn(int N, bool dw) {
+    // per CU: 3 workgroups of the 64-wide tile, 2 of the 128-wide, 1 of the 192-wide (LDS); a k-step's latency is hidden only by the
+    // other workgroups, so the 192-wide tile is kept for the fused depthwise case where it saves deriving the depthwise tile twice
+    if (N <= 64) return 64;
+    if (dw && N > 128 && N <= 192) return 192;
+    if (N <= 128 || N % 128 == 0) return 128;
+    return 64;
+}
+static bool x_env_flag(const char *name, bool dflt) {
+    const char *e = getenv(name);
+    return (e && e[0]) ? e[0] != '0' : dflt;
+}
 
 }   // namespace
 
@@ -452,8 +638,8 @@ struct yk_xplan {
     std::vector<void *> allocs;
     std::vector<int> outputs;
     unsigned *d_imgmax = nullptr;
-    uint32_t *d_amax = nullptr;        // [n_tensors][max_batch]
-    uint32_t *d_one = nullptr;         // [max_batch] bits of 1.0f (the normalised image)
+    uint32_t *d_amax = nullptr;        // [n_tensors][max_batch][XS]
+    uint32_t *d_one = nullptr;         // [max_batch][XS] bits of 1.0f (the normalised image)
 };
 
 static int x_alloc(yk_xplan *p, void **ptr, size_t bytes) {
@@ -475,6 +661,17 @@ static int x_upload_f(yk_xplan *p, const float *src, int n, float mul, const flo
     int rc = x_upload(p, &q, v.data(), v.size() * sizeof(float));
     *d = (const float *)q;
     return rc;
+}
+
+template <int BN, bool DW>
+static int x_launch_conv(const xconv_args &g, dim3 grid, unsigned lds, hipStream_t st) {
+    static unsigned allowed = 64 * 1024;                             // dynamic LDS above 64 KB has to be enabled per kernel
+    if (lds > allowed) {
+        YK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(xconv_kernel<BN, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((xconv_kernel<BN, DW>), grid, dim3(256), lds, st, g);
+    return YK_OK;
 }
 
 void yk_xplan_destroy(yk_xplan *p) {
@@ -537,9 +734,29 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             }
         }
     }
+    // DepthwiseConv2D(3x3) whose only consumer is the next op, a 1x1 stride-1 Conv2D: produced inside that conv's kernel
+    std::vector<int> dw_of(n_ops, -1);
+    std::vector<char> gone(n_tensors, 0);
+    // measured (K2, B=32, us fused vs depthwise + 1x1 launches): 24 ch 119 vs 109, 48 ch 67 vs 73, 96 ch (stride 1) 67 vs 93,
+    // 96 ch (stride 2) 50 vs 44, 192 ch 65 vs 58, 384 ch 73 vs 42: the fused workgroup has one wave per SIMD to hide the nine taps'
+    // latency and re-derives the depthwise tile for every N tile, so it only pays where the depthwise tensor is big and narrow
+    const int fuse_max_c = getenv("YK_X_FUSE_MAXC") ? atoi(getenv("YK_X_FUSE_MAXC")) : 96;
+    const int fuse_min_c = getenv("YK_X_FUSE_MINC") ? atoi(getenv("YK_X_FUSE_MINC")) : 48;
+    if (x_env_flag("YK_FUSE_DWPW", true))
+        for (int i = 0; i + 1 < n_ops; ++i) {
+            const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
+            const int y = o[YK_F_OUT];
+            if (o[YK_F_TYPE] == YK_OP_DWCONV && q[YK_F_TYPE] == YK_OP_CONV && q[YK_F_K] == 1 && q[YK_F_STRIDE] == 1 && q[YK_F_IN0] == y &&
+                p->T[y].uses == 1 && p->T[y].kind == XT_REAL && p->T[o[YK_F_IN0]].kind == XT_REAL && !p->T[o[YK_F_IN0]].is_input &&
+                p->T[y].cp * o[YK_F_STRIDE] <= fuse_max_c && p->T[y].cp >= fuse_min_c) {
+                dw_of[i + 1] = i;
+                skip[i] = 1;
+                gone[y] = 1;
+            }
+        }
     for (int i = 1; i < n_tensors; ++i) {
         xtens &t = p->T[i];
-        if (t.kind != XT_REAL) continue;
+        if (t.kind != XT_REAL || gone[i]) continue;
         bool folded = false;
         for (int k = 0; k < n_ops; ++k)
             if (ops[(size_t)k * YK_OP_FIELDS + YK_F_OUT] == i && add_of[k] >= 0) folded = true;
@@ -548,14 +765,14 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         if ((rc = x_alloc(p, (void **)&t.d, ((size_t)max_batch * t.h * t.w * pitch + 64) * sizeof(float)))) return fail(rc);
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * (size_t)n_tensors * max_batch))) return fail(rc);
+    if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * (size_t)n_tensors * max_batch * XS))) return fail(rc);
     {
-        std::vector<uint32_t> one(max_batch, 0x3f800000u);
+        std::vector<uint32_t> one((size_t)max_batch * XS, 0x3f800000u);
         void *q;
         if ((rc = x_upload(p, &q, one.data(), one.size() * 4))) return fail(rc);
         p->d_one = (uint32_t *)q;
     }
-    auto amax_of = [&](int tid) { return p->d_amax + (size_t)tid * max_batch; };
+    auto amax_of = [&](int tid) { return p->d_amax + (size_t)tid * max_batch * XS; };
     {
         xlaunch l;
         l.kind = XK_U8MAX;
@@ -607,6 +824,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             xconv_args &g = l.c;
             memset(&g, 0, sizeof(g));
             int s0 = xid, s1 = -1, up0 = 0;
+            const int32_t *dwo = dw_of[i] >= 0 ? ops + (size_t)dw_of[i] * YK_OP_FIELDS : nullptr;
+            if (dwo) s0 = dwo[YK_F_IN0];                              // fused depthwise producer: read ITS input
             if (X.kind == XT_CAT) {
                 s0 = X.src0;
                 s1 = X.src1;
@@ -660,6 +879,65 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
             g.amax_in0 = S0.is_input ? p->d_one : amax_of(s0);
             g.amax_in1 = S1 ? amax_of(s1) : nullptr;
+            if (dwo) {
+                // [11][c0p]: nine taps, BN scale, BN bias of the depthwise conv; bound of its output from the input's max
+                std::vector<float> par((size_t)11 * c0p, 0.f);
+                float gain = 0.f, off = 0.f, dalpha;
+                memcpy(&dalpha, &dwo[YK_F_ALPHA], 4);
+                for (int k = 0; k < c0; ++k) {
+                    float sw = 0.f;
+                    for (int t = 0; t < 9; ++t) {
+                        const float w = blob[dwo[YK_F_W_OFF] + (size_t)t * c0 + k];
+                        par[(size_t)t * c0p + k] = w;
+                        sw += fabsf(w);
+                    }
+                    const float sc = blob[dwo[YK_F_SCALE_OFF] + k], bs = blob[dwo[YK_F_BIAS_OFF] + k];
+                    par[(size_t)9 * c0p + k] = sc;
+                    par[(size_t)10 * c0p + k] = bs;
+                    gain = std::max(gain, fabsf(sc) * sw);
+                    off = std::max(off, fabsf(bs));
+                }
+                void *dp;
+                if ((rc = x_upload(p, &dp, par.data(), par.size() * sizeof(float)))) return fail(rc);
+                g.dw_par = (const float *)dp;
+                g.dw_Hi = S0.h; g.dw_Wi = S0.w;
+                g.dw_stride = dwo[YK_F_STRIDE]; g.dw_pad_t = dwo[YK_F_PAD_T]; g.dw_pad_l = dwo[YK_F_PAD_L];
+                yk_act_params(dwo[YK_F_ACT], dalpha, &g.dw_slope, &g.dw_cap);
+                g.dw_gain = gain * 1.0001f;
+                g.dw_off = off * 1.0001f;
+                l.dw = 1;
+            }
+            // tile shape, pixel patch and K split are fixed here, for max_batch: an image's arithmetic never depends on the batch
+            l.bn = x_pick_bn(co, l.dw != 0);
+            if (const char *e = getenv("YK_X_BN")) {
+                const int v = atoi(e);
+                if (v == 64 || v == 128 || v == 192) l.bn = v;
+            }
+            x_pick_patch(Y.h, Y.w, l.dw || ks == 3, &g.sr_sh, &g.sc_sh);
+            if (!x_env_flag("YK_X_PATCH", true)) g.sr_sh = g.sc_sh = 0;
+            g.TX = (Y.w + (1 << g.sc_sh) - 1) >> g.sc_sh;
+            g.TXY = g.TX * ((Y.h + (1 << g.sr_sh) - 1) >> g.sr_sh);
+            g.fd_txy = yk_make_fastdiv((uint32_t)g.TXY);
+            g.fd_tx = yk_make_fastdiv((uint32_t)g.TX);
+            l.lds = (unsigned)((size_t)2 * (2 * XBM + 2 * l.bn) * XLD * 2 + 4 * XBM * 4 + (l.dw ? (size_t)11 * c0p * 4 : 0));
+            {
+                const long mt = ((long)max_batch * g.TXY + (XBM >> (g.sr_sh + g.sc_sh)) - 1) / (XBM >> (g.sr_sh + g.sc_sh));
+                // a k-step is a dependent chain (loads -> split -> LDS -> MFMA), hidden only by other workgroups on the CU: small
+                // problems take the narrow tile (3 workgroups per CU) and share K out until there are ~3 workgroups per CU
+                if (!getenv("YK_X_BN") && mt * ((co + l.bn - 1) / l.bn) < 256) l.bn = 64;
+                l.lds = (unsigned)((size_t)2 * (2 * XBM + 2 * l.bn) * XLD * 2 + 4 * XBM * 4 + (l.dw ? (size_t)11 * c0p * 4 : 0));
+                const long tiles = mt * ((co + l.bn - 1) / l.bn);
+                const int nk = (g.K + XBK - 1) / XBK;
+                long sk = 1;
+                if (tiles < 384 && nk >= 16) sk = std::min<long>(std::min<long>(8, (768 + tiles - 1) / tiles), nk / 4);
+                if (const char *e = getenv("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nk));
+                g.splitk = (int)std::max<long>(1, sk);
+                if (g.splitk > 1) {
+                    void *sl;
+                    if ((rc = x_alloc(p, &sl, (size_t)g.splitk * tiles * (l.bn / 16) * 256 * 16))) return fail(rc);
+                    g.slab = (float *)sl;
+                }
+            }
             xtens *dst = &Y;
             int dst_id = yid;
             if (add_of[i] >= 0) {
@@ -678,10 +956,15 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 yk_set_error("op %d: output tensor not allocated", i);
                 return fail(YK_ERR_UNSUPPORTED);
             }
-            snprintf(nm, sizeof nm, "x:conv%dx%ds%d_%dto%d%s%s", ks, ks, g.stride, cin, co, g.res ? "+add" : "",
-                     S1 ? "+upcat" : (up0 ? "+up" : ""));
-            l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)cin * co;
-            l.bytes = ((double)X.h * X.w * cin + (double)Y.h * Y.w * co) * 4;
+            char tl[48];
+            snprintf(tl, sizeof tl, "[64x%d%s%s]", l.bn, (g.sr_sh + g.sc_sh) ? ",patch" : "", g.splitk > 1 ? ",splitk" : "");
+            if (dwo)
+                snprintf(nm, sizeof nm, "x:dw3x3s%d+conv1x1_%dto%d%s%s", g.dw_stride, cin, co, g.res ? "+add" : "", tl);
+            else
+                snprintf(nm, sizeof nm, "x:conv%dx%ds%d_%dto%d%s%s%s", ks, ks, g.stride, cin, co, g.res ? "+add" : "",
+                         S1 ? "+upcat" : (up0 ? "+up" : ""), tl);
+            l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)cin * co + (dwo ? 2.0 * Y.h * Y.w * 9 * cin : 0.0);
+            l.bytes = ((double)S0.h * S0.w * c0 + (S1 ? (double)S1->h * S1->w * c1 : 0.0) + (double)Y.h * Y.w * co) * 4;
         } else if (ty == YK_OP_DWCONV) {
             if (X.kind != XT_REAL || X.is_input) {
                 yk_set_error("op %d: depthwise conv on a view/input", i);
@@ -704,6 +987,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             yk_act_params(o[YK_F_ACT], alpha, &d.slope, &d.cap);
             d.out = Y.d;
             d.amax_out = amax_of(yid);
+            d.fd_g = yk_make_fastdiv((uint32_t)(cp >> 2));
+            d.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
             snprintf(nm, sizeof nm, "x:dw3x3s%d_%d", d.stride, c);
             l.flops = 2.0 * Y.h * Y.w * 9 * c;
             l.bytes = ((double)X.h * X.w * c + (double)Y.h * Y.w * c) * 4;
@@ -750,7 +1035,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
 }
 
 int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream_t st, hipEvent_t *ev) {
-    YK_HIP(hipMemsetAsync(p->d_amax, 0, sizeof(uint32_t) * p->T.size() * p->max_batch, st));
+    YK_HIP(hipMemsetAsync(p->d_amax, 0, sizeof(uint32_t) * p->T.size() * p->max_batch * XS, st));
     int li = 0;
     for (xlaunch &l : p->L) {
         if (ev) YK_HIP(hipEventRecord(ev[2 * li], st));
@@ -771,14 +1056,26 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
         } break;
         case XK_CONV: {
             xconv_args g = l.c;
+            g.B = batch;
             g.M = batch * l.Ho * l.Wo;
-            hipLaunchKernelGGL(xconv_kernel, dim3((g.M + XBM - 1) / XBM, (g.N + XBN - 1) / XBN), dim3(256), 0, st, g);
+            const int per = XBM >> (g.sr_sh + g.sc_sh);
+            dim3 grid((unsigned)(((long)batch * g.TXY + per - 1) / per), (unsigned)((g.N + l.bn - 1) / l.bn), (unsigned)g.splitk);
+            for (int ph = g.splitk > 1 ? 1 : 0; ph <= (g.splitk > 1 ? 2 : 0); ++ph) {
+                g.phase = ph;
+                if (ph == 2) grid.z = 1;
+                int rc = YK_OK;
+                if (l.dw) rc = l.bn == 64 ? x_launch_conv<64, true>(g, grid, l.lds, st) : l.bn == 128 ? x_launch_conv<128, true>(g, grid, l.lds, st)
+                                                                                                    : x_launch_conv<192, true>(g, grid, l.lds, st);
+                else rc = l.bn == 64 ? x_launch_conv<64, false>(g, grid, l.lds, st) : l.bn == 128 ? x_launch_conv<128, false>(g, grid, l.lds, st)
+                                                                                                   : x_launch_conv<192, false>(g, grid, l.lds, st);
+                if (rc) return rc;
+            }
         } break;
         case XK_DW: {
             xdw_args d = l.d;
             d.B = batch;
-            const size_t total = (size_t)batch * d.Ho * d.Wo * (d.Cp >> 2);
-            hipLaunchKernelGGL(xdw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d);
+            const unsigned per_image = (unsigned)d.Ho * d.Wo * (d.Cp >> 2);
+            hipLaunchKernelGGL(xdw_kernel, dim3((per_image + 255) / 256, batch), dim3(256), 0, st, d);
         } break;
         case XK_POOL: {
             xpool_args q = l.p;

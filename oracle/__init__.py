@@ -50,7 +50,15 @@ def lib() -> C.CDLL:
         _LIB.yk_ref_forward_ex.restype = C.c_int
         _LIB.yk_ref_f16_round.restype = C.c_float
         _LIB.yk_ref_f16_round.argtypes = [C.c_float]
+        _LIB.yk_ref_set_threads.restype = C.c_int
+        _LIB.yk_ref_set_threads(int(os.environ.get('ORACLE_THREADS', min(32, os.cpu_count() or 1))))
     return _LIB
+
+
+def set_threads(n: int) -> int:
+    """OpenMP team size of the C oracle's conv loops (default min(32, cpus): a team of every logical CPU spin-waits at each loop's
+    barrier and slows down 10x on a host shared with other jobs).  Returns the value in effect."""
+    return int(lib().yk_ref_set_threads(int(n)))
 
 
 def have_ref() -> bool:

@@ -76,6 +76,21 @@ typedef struct {
 /* returns 0 ok, <0 on error.  input: fp32 [batch][H][W][3] already normalised.
  * out_ptrs[i]: caller buffer for tensor out_ids[i], fp32 [batch][h][w][c].
  * dump_id >= 0 additionally copies that tensor into dump (fp32 NHWC). */
+/* OpenMP team size of this library's loops.  The default (every logical CPU, spinning at barriers) collapses on a shared host; the
+ * python wrapper caps it at 32 unless ORACLE_THREADS says otherwise, bench.py's cpu_baseline asks for all cores explicitly. */
+#ifdef _OPENMP
+#include <omp.h>
+int yk_ref_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+#else
+int yk_ref_set_threads(int n) {
+    (void)n;
+    return 1;
+}
+#endif
+
 int yk_ref_forward_ex(const int32_t *ops, int n_ops, const int32_t *tensors, int n_t, const float *blob_in,
                       size_t blob_len, int n_in, const int32_t *in_ids, const float *const *in_ptrs, int batch,
                       int emulate_f16, const int32_t *out_ids, int n_out, float **out_ptrs, int dump_id, float *dump) {

@@ -167,7 +167,7 @@ def test_f16x2_whole_network_undamped_vs_fp32_oracle(name, shape, alpha, B, u8):
     frames = np.random.default_rng(0).integers(0, 256, (B, *shape), dtype=np.uint8)
     x = oracle.normalise_u8(frames)
     every = [op['out'] for op in spec.ops if op['type'] in (ns.OP_CONV, ns.OP_DWCONV, ns.OP_ADD, ns.OP_MAXPOOL)]
-    pick = every[::max(1, len(every) // 12)]
+    pick = every[::max(1, len(every) // 6)]     # each picked tensor costs one pass of the CPU oracle
     outs, mids, names = _run_plan(spec, w, x_u8=frames if u8 else None, x_f32=None if u8 else x, want=pick, precision='f16x2')
     assert all(n.startswith('x:') or n == 'u8_max' for n in names)
     tol = TOL_X2_V2 if name == 'yolo_mobilev2' else TOL_X2
