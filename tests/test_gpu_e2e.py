@@ -65,17 +65,27 @@ def _match(got, ref_dets, ref_scores_all, obj, hw):
 
 
 def _assert_north_star(dets, ref_dets, tag):
-    """Same detections in the same order; scores within 1e-3; corners within 1e-3 of the box size (w,h = exp(t)*anchor scales
-    the logit error by the box size itself; boxes are in pixels of the original image)."""
+    """The same SET of detections (class, box) per image; scores within 1e-3; corners within 1e-3 of the box size (w,h = exp(t)*anchor
+    scales the logit error by the box size itself; boxes are in pixels of the original image).  Rows are compared in place; where two
+    detections of a class have scores closer than the logit error their order inside the class is not defined (350 random-weight
+    detections per image: it happens), so rows that differ in place are paired one-to-one by class and nearest box instead."""
     n = 0
     for b, (g, r) in enumerate(zip(dets, ref_dets)):
         assert len(g) == len(r), (tag, b, len(g), len(r))
         if not len(r):
             continue
         assert np.array_equal(g[:, 5], r[:, 5]), (tag, b)                       # class of every detection, class-major order
-        assert np.abs(g[:, 4] - r[:, 4]).max() <= NORTH_STAR, (tag, b, np.abs(g[:, 4] - r[:, 4]).max())
-        size = np.maximum(np.maximum(r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]), 1.0)[:, None]
-        assert (np.abs(g[:, :4] - r[:, :4]) / size).max() <= NORTH_STAR, (tag, b)   # the same box, not a neighbour
+        size = np.maximum(np.maximum(r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]), 1.0)
+        same = (np.abs(g[:, :4] - r[:, :4]).max(1) / size <= NORTH_STAR) & (np.abs(g[:, 4] - r[:, 4]) <= NORTH_STAR)
+        free = list(np.nonzero(~same)[0])
+        assert len(free) <= max(2, len(r) // 50), (tag, b, len(free))           # reordering is the exception
+        for i in np.nonzero(~same)[0]:
+            cand = [j for j in free if g[j, 5] == r[i, 5]]
+            assert cand, (tag, b, i)
+            eb = [np.abs(g[j, :4] - r[i, :4]).max() / size[i] for j in cand]
+            j = cand[int(np.argmin(eb))]
+            assert min(eb) <= NORTH_STAR and abs(g[j, 4] - r[i, 4]) <= NORTH_STAR, (tag, b, i, min(eb), abs(g[j, 4] - r[i, 4]))
+            free.remove(j)
         n += len(r)
     return n
 
