@@ -759,11 +759,20 @@ static int launch_cfg(const igemm_args &a, hipStream_t st) {
     static const bool dma_on = yk_dev_env("YK_DMA") ? yk_dev_env("YK_DMA")[0] != '0' : true;      // LDS-DMA operand tiles (YK_DMA=0: register staging)
     if constexpr (UNI_OK && BK == 64 && !F32 && (BM / 8) % (WM * WN) == 0 && (BN / 8) % (WM * WN) == 0) {
         static const bool pipe_on = yk_dev_env("YK_PIPE") ? yk_dev_env("YK_PIPE")[0] != '0' : true;       // multi-stage LDS-DMA ring (yk_igemm_pipe.h)
-        constexpr int NS = 2;   // measured: 3-4 stages cost occupancy and lose 10-20 % everywhere (52x52 128->256: 2 stages 551, 3 stages 457 TF/s)
+        // ring depth: 2 stages wherever the grid fills the CUs several times over (3-4 stages cost occupancy and lose 10-20 % there:
+        // 52x52 128->256: 2 stages 551, 3 stages 457 TF/s); a grid of at most ~2 workgroups per CU is latency-bound instead - each
+        // k-step waits for the DMA issued one step earlier - and takes 4 stages (three k-steps of loads in flight) where two such
+        // workgroups still fit a CU's LDS: the 64x64 tile (7x10 768->192 3x3: 26.3 -> 20.3 us; with the 64x128 tile, one workgroup
+        // per CU, the upsample+concat conv went 27 -> 38 us)
         static const int ns_env = yk_dev_env("YK_NS") ? atoi(yk_dev_env("YK_NS")) : 0;                    // dev sweep
-        if (dma_on && pipe_on && uni && ns_env == 2) return launch_pipe<BM, BN, WM, WN, 2>(a, st);
-        if (dma_on && pipe_on && uni && ns_env == 3) return launch_pipe<BM, BN, WM, WN, 3>(a, st);
-        if (dma_on && pipe_on && uni) return launch_pipe<BM, BN, WM, WN, NS>(a, st);
+        const long wgs = (long)grid.x * grid.y * grid.z;
+        const int ns = ns_env ? ns_env : (wgs <= 640 && (BM + BN) <= 128 ? 4 : 2);
+        if constexpr (BM + BN <= 128)
+            if (dma_on && pipe_on && uni && ns == 4) return launch_pipe<BM, BN, WM, WN, 4>(a, st);
+#ifdef YK_DEV
+        if (dma_on && pipe_on && uni && ns == 3) return launch_pipe<BM, BN, WM, WN, 3>(a, st);
+#endif
+        if (dma_on && pipe_on && uni) return launch_pipe<BM, BN, WM, WN, 2>(a, st);
     }
     static const bool lin_on = yk_dev_env("YK_LIN") ? yk_dev_env("YK_LIN")[0] != '0' : true;
     constexpr bool LIN_OK = UNI_OK && ((BM * (BK / 8)) % (64 * WM * WN) == 0) && ((BN * (BK / 8)) % (64 * WM * WN) == 0);
