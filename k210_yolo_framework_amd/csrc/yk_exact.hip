@@ -130,15 +130,6 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     if (DW)
         for (int i = tid; i < 11 * a.c0p / 4; i += 256) reinterpret_cast<float4 *>(dwl)[i] = reinterpret_cast<const float4 *>(a.dw_par)[i];
     __syncthreads();
-    if (wid == 0) {                                                // operand exponent of every image this tile touches (usually one)
-        const int bl = sb[XBM - 1];
-        for (int b = sb[0]; b <= bl; ++b) {
-            const int e = x_img_exp(a, b, DW);
-            if (lane == 0) sexp[b - sb[0]] = e;
-        }
-    }
-    __syncthreads();
-
     // this thread's A row (one output pixel) and its operand scale
     const int m = spix[row];
     const bool mok = m >= 0;
@@ -150,7 +141,6 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     if (mok) {
         const uint32_t rem = m - rb * a.HoWo;
         const uint32_t oy = x_div(rem, a.fd_wo), ox = rem - oy * a.Wo;
-        sdown = x_pow2(-sexp[rb - b0]);
         if (DW) {
             const int y0 = (int)oy * a.dw_stride - a.dw_pad_t, x0 = (int)ox * a.dw_stride - a.dw_pad_l;
 #pragma unroll
@@ -166,11 +156,14 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     const int per = (nk + a.splitk - 1) / a.splitk;
     const int kb = blockIdx.z * per, ke = a.phase == 2 ? kb : min(nk, kb + per);
     int kch = kb * XBK + kc * 8, ktap = 0;
-    float4 ra0, ra1;
+    struct xregs {                                                 // one k-step of operands on their way from global memory to LDS
+        float4 ra0, ra1;
+        half8 rbh[NB], rbl[NB];
+    };
+    xregs R0, R1;
     float4 xin[DW ? 9 : 1][2];
     int dwch = 0;
-    half8 rbh[NB], rbl[NB];
-    auto gload = [&](int k0) {
+    auto gload = [&](xregs &R, int k0) {
         if (DW) {
             dwch = k0 + kc * 8;
             const bool cok = dwch < a.c0p;
@@ -190,7 +183,7 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
             }
             const int ky = (a.ks == 3) ? ktap / 3 : 0, kx = ktap - ky * a.ks;
             const int iy = riy + ky, ix = rix + kx;
-            ra0 = ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            R.ra0 = R.ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ktap < taps && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
                 const float *p;
                 if (kch < a.c0p) {
@@ -199,8 +192,8 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
                 } else {
                     p = a.in1 + ((size_t)(rb * a.Hi + iy) * a.Wi + ix) * a.c1p + (kch - a.c0p);
                 }
-                ra0 = *reinterpret_cast<const float4 *>(p);
-                ra1 = *reinterpret_cast<const float4 *>(p + 4);
+                R.ra0 = *reinterpret_cast<const float4 *>(p);
+                R.ra1 = *reinterpret_cast<const float4 *>(p + 4);
             }
             kch += XBK;
         }
@@ -208,14 +201,14 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int nrow = n0 + row + 64 * i;
-            rbh[i] = rbl[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            R.rbh[i] = R.rbl[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             if (nrow < a.N && k < a.K) {
-                rbh[i] = *reinterpret_cast<const half8 *>(a.w_hi + (size_t)nrow * a.K + k);
-                rbl[i] = *reinterpret_cast<const half8 *>(a.w_lo + (size_t)nrow * a.K + k);
+                R.rbh[i] = *reinterpret_cast<const half8 *>(a.w_hi + (size_t)nrow * a.K + k);
+                R.rbl[i] = *reinterpret_cast<const half8 *>(a.w_lo + (size_t)nrow * a.K + k);
             }
         }
     };
-    auto sstore = [&](int stage) {
+    auto sstore = [&](xregs &R, int stage) {
         yk_half *S = lds + stage * STG;
         float v[8];
         if (DW) {
@@ -241,8 +234,8 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = acc[j] * sdown;
         } else {
-            v[0] = ra0.x * sdown; v[1] = ra0.y * sdown; v[2] = ra0.z * sdown; v[3] = ra0.w * sdown;
-            v[4] = ra1.x * sdown; v[5] = ra1.y * sdown; v[6] = ra1.z * sdown; v[7] = ra1.w * sdown;
+            v[0] = R.ra0.x * sdown; v[1] = R.ra0.y * sdown; v[2] = R.ra0.z * sdown; v[3] = R.ra0.w * sdown;
+            v[4] = R.ra1.x * sdown; v[5] = R.ra1.y * sdown; v[6] = R.ra1.z * sdown; v[7] = R.ra1.w * sdown;
         }
         half8 hi, lo;
 #pragma unroll
@@ -254,8 +247,8 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
         *reinterpret_cast<half8 *>(S + XBM * XLD + row * XLD + kc * 8) = lo;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            *reinterpret_cast<half8 *>(S + 2 * XBM * XLD + (row + 64 * i) * XLD + kc * 8) = rbh[i];
-            *reinterpret_cast<half8 *>(S + (2 * XBM + BN) * XLD + (row + 64 * i) * XLD + kc * 8) = rbl[i];
+            *reinterpret_cast<half8 *>(S + 2 * XBM * XLD + (row + 64 * i) * XLD + kc * 8) = R.rbh[i];
+            *reinterpret_cast<half8 *>(S + (2 * XBM + BN) * XLD + (row + 64 * i) * XLD + kc * 8) = R.rbl[i];
         }
     };
     floatx4 acc[2][NT];
@@ -264,14 +257,8 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    if (kb < ke) {
-        gload(kb * XBK);
-        sstore(0);
-    }
-    __syncthreads();
-    for (int kt = kb; kt < ke; ++kt) {
-        if (kt + 1 < ke) gload((kt + 1) * XBK);
-        const yk_half *S = lds + ((kt - kb) & 1) * STG;
+    auto mma = [&](int stage) {
+        const yk_half *S = lds + stage * STG;
         half8 xh[2], xl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -289,8 +276,44 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < ke) sstore(((kt - kb) + 1) & 1);
-        __syncthreads();
+    };
+    // a workgroup's life is a chain of memory round trips (tile map -> exponent slots -> operands -> ... -> scale / bias -> stores) and
+    // with short K that chain, not the MFMAs, is the kernel's time: the first k-step's loads go out BEFORE the exponent slots are read
+    if (kb < ke) gload(R0, kb * XBK);
+    if (wid == 0) {                                                // operand exponent of every image this tile touches (usually one)
+        const int bl = sb[XBM - 1];
+        for (int b = b0; b <= bl; ++b) {
+            const int e = x_img_exp(a, b, DW);
+            if (lane == 0) sexp[b - b0] = e;
+        }
+    }
+    __syncthreads();
+    if (mok) sdown = x_pow2(-sexp[rb - b0]);
+    if (kb < ke) sstore(R0, 0);
+    __syncthreads();
+    if (DW) {
+        // the nine taps of the next k-step fly under this step's MFMAs (a second set would cost 72 registers; these layers have 1-3 steps)
+        for (int kt = kb; kt < ke; ++kt) {
+            if (kt + 1 < ke) gload(R0, (kt + 1) * XBK);
+            mma((kt - kb) & 1);
+            if (kt + 1 < ke) sstore(R0, ((kt - kb) + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // two k-steps of global loads in flight (register sets R0 / R1): a step's operands were requested two steps before they are
+        // split and stored, so the L2 / HBM round trip overlaps two rounds of MFMAs instead of one
+        if (kb + 1 < ke) gload(R1, (kb + 1) * XBK);
+        for (int kt = kb; kt < ke; kt += 2) {
+            if (kt + 2 < ke) gload(R0, (kt + 2) * XBK);
+            mma(0);
+            if (kt + 1 < ke) sstore(R1, 1);
+            __syncthreads();
+            if (kt + 1 >= ke) break;
+            if (kt + 3 < ke) gload(R1, (kt + 3) * XBK);
+            mma(1);
+            if (kt + 2 < ke) sstore(R0, 0);
+            __syncthreads();
+        }
     }
     if (a.splitk > 1) {
         // phase 1: partial sums -> slab[z][tile][reg][thread]; phase 2 (a second launch of this kernel, grid.z = 1, no k loop): add the

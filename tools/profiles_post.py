@@ -37,3 +37,31 @@ if os.path.exists(st):
     with open(st) as a, open(os.path.join(root, 'profiles', f'{tag}_kernel_stats.csv'), 'w') as b:
         b.write(a.read())
 print('ok', len(out), 'launches; total traffic MB/step', sum(r[6] for r in out) / 1e6)
+
+# per-launch durations from the kernel trace of the same script (dispatch order, last `steps` steps)
+tr = os.path.join(src, 'stats', 'p_kernel_trace.csv')
+if os.path.exists(tr):
+    rows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r['Start_Timestamp']))
+    n_steps = min(40, len(rows) // len(L) - 2)
+    rows = rows[-len(L) * n_steps:]
+    acc = collections.defaultdict(list)
+    for i, r in enumerate(rows):
+        acc[i % len(L)].append(((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r))
+    with open(os.path.join(root, 'profiles', f'{tag}_kernel_trace_per_launch.csv'), 'w', newline='') as fh:
+        fh.write('# rocprofv3 --kernel-trace on tools/one_step.py 50 (= bench.py step, B=32, one batch in flight): duration per launch of '
+                 f'the step, dispatch order, last {n_steps} steps\n')
+        wr = csv.writer(fh)
+        wr.writerow(['launch', 'name', 'kernel', 'avg_us', 'min_us', 'max_us', 'vgpr', 'lds'])
+        tot = 0.0
+        for i, nm in enumerate(L):
+            d = [v[0] for v in acc[i]]
+            r0 = acc[i][0][1]
+            tot += sum(d) / len(d)
+            wr.writerow([i, nm, r0['Kernel_Name'][:90], round(sum(d) / len(d), 2), round(min(d), 2), round(max(d), 2), r0['VGPR_Count'],
+                         r0['LDS_Block_Size']])
+    print('per-launch trace: sum of averages %.1f us' % tot)
+for extra, dst in (('train/p_kernel_stats.csv', f'{tag}_train_kernel_stats.csv'), ('bench_line.json', f'{tag}_bench_line.json'),
+                   ('x2_per_launch.txt', f'{tag}_f16x2_per_launch.txt'), ('drift_v1.txt', f'{tag}_fp16_drift_per_layer.txt')):
+    if os.path.exists(os.path.join(src, extra)):
+        with open(os.path.join(src, extra)) as a, open(os.path.join(root, 'profiles', dst), 'w') as b:
+            b.write(a.read())
