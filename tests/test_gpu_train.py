@@ -348,6 +348,20 @@ def test_training_step_is_bitwise_reproducible():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
 
 
+def test_graph_replayed_step_equals_the_eager_step_bitwise():
+    """Trainer(use_graph=True) captures forward + loss + backward once (after an eager first step) and replays it: the same kernels
+    on the same buffers in the same order, so gradients and parameters after three steps equal the eager run bit for bit."""
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case('yolo_mobilev1', (64, 96), 4, 0.5, 22)
+    runs = []
+    for graph in (False, True):
+        tr = Trainer(spec, w, h.anchors, 4, use_graph=graph)
+        for _ in range(3):                                                    # step 1 eager, step 2 captured + replayed, step 3 replayed
+            tr.step(_cu(x), [_cu(y) for y in yt])
+        runs.append((tr.G.cpu().numpy().copy(), tr.P.cpu().numpy().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+
+
 def test_full_size_config3_step_mobilev2_b16_loss_and_gradient_direction():
     """BASELINE configs[3] at full size (yolo_mobilev2 1.0, 224x320, 16 images).  With ~1e8 activations some gates always flip
     between fp32 and float64, so gradients are compared by direction and norm per tensor instead of element-wise."""
