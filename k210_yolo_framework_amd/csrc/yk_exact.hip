@@ -763,8 +763,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     // measured (K2, B=32, us fused vs depthwise + 1x1 launches): 24 ch 119 vs 109, 48 ch 67 vs 73, 96 ch (stride 1) 67 vs 93,
     // 96 ch (stride 2) 50 vs 44, 192 ch 65 vs 58, 384 ch 73 vs 42: the fused workgroup has one wave per SIMD to hide the nine taps'
     // latency and re-derives the depthwise tile for every N tile, so it only pays where the depthwise tensor is big and narrow
-    const int fuse_max_c = getenv("YK_X_FUSE_MAXC") ? atoi(getenv("YK_X_FUSE_MAXC")) : 96;
-    const int fuse_min_c = getenv("YK_X_FUSE_MINC") ? atoi(getenv("YK_X_FUSE_MINC")) : 48;
+    const int fuse_max_c = yk_dev_env("YK_X_FUSE_MAXC") ? atoi(yk_dev_env("YK_X_FUSE_MAXC")) : 96;
+    const int fuse_min_c = yk_dev_env("YK_X_FUSE_MINC") ? atoi(yk_dev_env("YK_X_FUSE_MINC")) : 48;
     if (x_env_flag("YK_FUSE_DWPW", true))
         for (int i = 0; i + 1 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
@@ -932,12 +932,13 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             }
             // tile shape, pixel patch and K split are fixed here, for max_batch: an image's arithmetic never depends on the batch
             l.bn = x_pick_bn(co, l.dw != 0);
-            if (const char *e = getenv("YK_X_BN")) {
+            if (const char *e = yk_dev_env("YK_X_BN")) {
                 const int v = atoi(e);
                 if (v == 64 || v == 128 || v == 192) l.bn = v;
             }
             x_pick_patch(Y.h, Y.w, l.dw || ks == 3, &g.sr_sh, &g.sc_sh);
-            if (!x_env_flag("YK_X_PATCH", true)) g.sr_sh = g.sc_sh = 0;
+            if (const char *e = yk_dev_env("YK_X_PATCH"))
+                if (e[0] == '0') g.sr_sh = g.sc_sh = 0;
             g.TX = (Y.w + (1 << g.sc_sh) - 1) >> g.sc_sh;
             g.TXY = g.TX * ((Y.h + (1 << g.sr_sh) - 1) >> g.sr_sh);
             g.fd_txy = yk_make_fastdiv((uint32_t)g.TXY);
@@ -947,13 +948,13 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 const long mt = ((long)max_batch * g.TXY + (XBM >> (g.sr_sh + g.sc_sh)) - 1) / (XBM >> (g.sr_sh + g.sc_sh));
                 // a k-step is a dependent chain (loads -> split -> LDS -> MFMA), hidden only by other workgroups on the CU: small
                 // problems take the narrow tile (3 workgroups per CU) and share K out until there are ~3 workgroups per CU
-                if (!getenv("YK_X_BN") && mt * ((co + l.bn - 1) / l.bn) < 256) l.bn = 64;
+                if (!yk_dev_env("YK_X_BN") && mt * ((co + l.bn - 1) / l.bn) < 256) l.bn = 64;
                 l.lds = (unsigned)((size_t)2 * (2 * XBM + 2 * l.bn) * XLD * 2 + 4 * XBM * 4 + (l.dw ? (size_t)11 * c0p * 4 : 0));
                 const long tiles = mt * ((co + l.bn - 1) / l.bn);
                 const int nk = (g.K + XBK - 1) / XBK;
                 long sk = 1;
                 if (tiles < 384 && nk >= 16) sk = std::min<long>(std::min<long>(8, (768 + tiles - 1) / tiles), nk / 4);
-                if (const char *e = getenv("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nk));
+                if (const char *e = yk_dev_env("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nk));
                 g.splitk = (int)std::max<long>(1, sk);
                 if (g.splitk > 1) {
                     void *sl;
