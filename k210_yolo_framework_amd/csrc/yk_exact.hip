@@ -159,23 +159,28 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     struct xregs {                                                 // one k-step of operands on their way from global memory to LDS
         float4 ra0, ra1;
         half8 rbh[NB], rbl[NB];
+        bool aok, bok[NB];                                         // dead loads are zeroed when the registers are consumed (sstore)
     };
     xregs R0, R1;
     float4 xin[DW ? 9 : 1][2];
     int dwch = 0;
+    unsigned dwmask = 0;                                           // taps of the staged depthwise step that are real
+    // every load below is UNCONDITIONAL (dead ones read a safe address and are zeroed by a select afterwards): a load inside a branch
+    // makes the compiler drain the memory queue (s_waitcnt vmcnt(0)) at the join, which serialises the prefetch it was meant to be
+    const float4 f4z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const half8 h8z = half8{0, 0, 0, 0, 0, 0, 0, 0};
     auto gload = [&](xregs &R, int k0) {
         if (DW) {
             dwch = k0 + kc * 8;
             const bool cok = dwch < a.c0p;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                xin[t][0] = xin[t][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok && ((vmask >> t) & 1u)) {
-                    const float *p = dwbase + ((t / 3) * a.dw_Wi + (t % 3)) * a.c0p + dwch;
-                    xin[t][0] = *reinterpret_cast<const float4 *>(p);
-                    xin[t][1] = *reinterpret_cast<const float4 *>(p + 4);
-                }
+                const bool ok = cok && ((vmask >> t) & 1u);
+                const float *p = ok ? dwbase + ((t / 3) * a.dw_Wi + (t % 3)) * a.c0p + dwch : a.in0;
+                xin[t][0] = *reinterpret_cast<const float4 *>(p);
+                xin[t][1] = *reinterpret_cast<const float4 *>(p + 4);
             }
+            dwmask = cok ? vmask : 0u;
         } else {
             while (kch >= Ctp) {
                 kch -= Ctp;
@@ -183,29 +188,26 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
             }
             const int ky = (a.ks == 3) ? ktap / 3 : 0, kx = ktap - ky * a.ks;
             const int iy = riy + ky, ix = rix + kx;
-            R.ra0 = R.ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ktap < taps && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
-                const float *p;
-                if (kch < a.c0p) {
-                    const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
-                    p = a.in0 + ((size_t)(rb * H0 + sy) * W0 + sx) * a.c0p + kch;
-                } else {
-                    p = a.in1 + ((size_t)(rb * a.Hi + iy) * a.Wi + ix) * a.c1p + (kch - a.c0p);
-                }
-                R.ra0 = *reinterpret_cast<const float4 *>(p);
-                R.ra1 = *reinterpret_cast<const float4 *>(p + 4);
-            }
+            const bool ok = ktap < taps && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+            const bool first = kch < a.c0p;
+            const int sy = a.up0 ? (iy >> 1) : iy, sx = a.up0 ? (ix >> 1) : ix;
+            const float *p0 = a.in0 + ((long long)(rb * H0 + sy) * W0 + sx) * a.c0p + kch;
+            const float *p1 = a.in1 + ((long long)(rb * a.Hi + iy) * a.Wi + ix) * a.c1p + (kch - a.c0p);
+            const float *p = ok ? (first ? p0 : p1) : a.in0;
+            R.ra0 = *reinterpret_cast<const float4 *>(p);
+            R.ra1 = *reinterpret_cast<const float4 *>(p + 4);
+            R.aok = ok;
             kch += XBK;
         }
         const int k = k0 + kc * 8;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int nrow = n0 + row + 64 * i;
-            R.rbh[i] = R.rbl[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (nrow < a.N && k < a.K) {
-                R.rbh[i] = *reinterpret_cast<const half8 *>(a.w_hi + (size_t)nrow * a.K + k);
-                R.rbl[i] = *reinterpret_cast<const half8 *>(a.w_lo + (size_t)nrow * a.K + k);
-            }
+            const bool ok = nrow < a.N && k < a.K;
+            const size_t at = ok ? (size_t)nrow * a.K + k : 0;
+            R.rbh[i] = *reinterpret_cast<const half8 *>(a.w_hi + at);
+            R.rbl[i] = *reinterpret_cast<const half8 *>(a.w_lo + at);
+            R.bok[i] = ok;
         }
     };
     auto sstore = [&](xregs &R, int stage) {
@@ -216,16 +218,18 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
             if (dwch < a.c0p) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
+                    const bool live = (dwmask >> t) & 1u;                          // dead taps were read from a safe address
+                    const float4 x0 = live ? xin[t][0] : f4z, x1 = live ? xin[t][1] : f4z;
                     const float4 w0 = *reinterpret_cast<const float4 *>(dwl + t * a.c0p + dwch);
                     const float4 w1 = *reinterpret_cast<const float4 *>(dwl + t * a.c0p + dwch + 4);
-                    acc[0] = fmaf(xin[t][0].x, w0.x, acc[0]);
-                    acc[1] = fmaf(xin[t][0].y, w0.y, acc[1]);
-                    acc[2] = fmaf(xin[t][0].z, w0.z, acc[2]);
-                    acc[3] = fmaf(xin[t][0].w, w0.w, acc[3]);
-                    acc[4] = fmaf(xin[t][1].x, w1.x, acc[4]);
-                    acc[5] = fmaf(xin[t][1].y, w1.y, acc[5]);
-                    acc[6] = fmaf(xin[t][1].z, w1.z, acc[6]);
-                    acc[7] = fmaf(xin[t][1].w, w1.w, acc[7]);
+                    acc[0] = fmaf(x0.x, w0.x, acc[0]);
+                    acc[1] = fmaf(x0.y, w0.y, acc[1]);
+                    acc[2] = fmaf(x0.z, w0.z, acc[2]);
+                    acc[3] = fmaf(x0.w, w0.w, acc[3]);
+                    acc[4] = fmaf(x1.x, w1.x, acc[4]);
+                    acc[5] = fmaf(x1.y, w1.y, acc[5]);
+                    acc[6] = fmaf(x1.z, w1.z, acc[6]);
+                    acc[7] = fmaf(x1.w, w1.w, acc[7]);
                 }
                 const float *sc = dwl + 9 * a.c0p + dwch, *bs = dwl + 10 * a.c0p + dwch;
 #pragma unroll
@@ -234,8 +238,9 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = acc[j] * sdown;
         } else {
-            v[0] = R.ra0.x * sdown; v[1] = R.ra0.y * sdown; v[2] = R.ra0.z * sdown; v[3] = R.ra0.w * sdown;
-            v[4] = R.ra1.x * sdown; v[5] = R.ra1.y * sdown; v[6] = R.ra1.z * sdown; v[7] = R.ra1.w * sdown;
+            const float4 q0 = R.aok ? R.ra0 : f4z, q1 = R.aok ? R.ra1 : f4z;
+            v[0] = q0.x * sdown; v[1] = q0.y * sdown; v[2] = q0.z * sdown; v[3] = q0.w * sdown;
+            v[4] = q1.x * sdown; v[5] = q1.y * sdown; v[6] = q1.z * sdown; v[7] = q1.w * sdown;
         }
         half8 hi, lo;
 #pragma unroll
@@ -247,8 +252,8 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
         *reinterpret_cast<half8 *>(S + XBM * XLD + row * XLD + kc * 8) = lo;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            *reinterpret_cast<half8 *>(S + 2 * XBM * XLD + (row + 64 * i) * XLD + kc * 8) = R.rbh[i];
-            *reinterpret_cast<half8 *>(S + (2 * XBM + BN) * XLD + (row + 64 * i) * XLD + kc * 8) = R.rbl[i];
+            *reinterpret_cast<half8 *>(S + 2 * XBM * XLD + (row + 64 * i) * XLD + kc * 8) = R.bok[i] ? R.rbh[i] : h8z;
+            *reinterpret_cast<half8 *>(S + (2 * XBM + BN) * XLD + (row + 64 * i) * XLD + kc * 8) = R.bok[i] ? R.rbl[i] : h8z;
         }
     };
     floatx4 acc[2][NT];
@@ -291,10 +296,12 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     if (mok) sdown = x_pow2(-sexp[rb - b0]);
     if (kb < ke) sstore(R0, 0);
     __syncthreads();
+    // gload() is called UNCONDITIONALLY in the loops below (a step past the end reads safe addresses and is never stored): with the
+    // loads in a branch the compiler cannot count them across the join and waits for ALL outstanding loads before issuing new ones
     if (DW) {
         // the nine taps of the next k-step fly under this step's MFMAs (a second set would cost 72 registers; these layers have 1-3 steps)
         for (int kt = kb; kt < ke; ++kt) {
-            if (kt + 1 < ke) gload(R0, (kt + 1) * XBK);
+            gload(R0, (kt + 1) * XBK);
             mma((kt - kb) & 1);
             if (kt + 1 < ke) sstore(R0, ((kt - kb) + 1) & 1);
             __syncthreads();
@@ -302,14 +309,14 @@ __global__ void __launch_bounds__(256) xconv_kernel(const xconv_args a) {
     } else {
         // two k-steps of global loads in flight (register sets R0 / R1): a step's operands were requested two steps before they are
         // split and stored, so the L2 / HBM round trip overlaps two rounds of MFMAs instead of one
-        if (kb + 1 < ke) gload(R1, (kb + 1) * XBK);
+        gload(R1, (kb + 1) * XBK);
         for (int kt = kb; kt < ke; kt += 2) {
-            if (kt + 2 < ke) gload(R0, (kt + 2) * XBK);
+            gload(R0, (kt + 2) * XBK);
             mma(0);
             if (kt + 1 < ke) sstore(R1, 1);
             __syncthreads();
             if (kt + 1 >= ke) break;
-            if (kt + 3 < ke) gload(R1, (kt + 3) * XBK);
+            gload(R1, (kt + 3) * XBK);
             mma(1);
             if (kt + 2 < ke) sstore(R0, 0);
             __syncthreads();
