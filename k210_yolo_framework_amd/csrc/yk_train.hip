@@ -125,6 +125,30 @@ __global__ void __launch_bounds__(256) splitk_sum_kernel(const float *__restrict
     *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
 }
 
+// Same sum for SMALL outputs with many slabs (the weight gradients of the early layers: a 32x16 result reduced over 64 slabs): the
+// kernel above would be two workgroups of threads each walking 64 dependent-latency loads.  Here 16 lanes share one output: lane j
+// adds slabs j, j+16, ... in order, then the 16 partial sums are added in lane order through LDS - a fixed order, so still bitwise
+// reproducible.  block = 16 (slab lanes) x 16 (outputs).
+__global__ void __launch_bounds__(256) splitk_sum16_kernel(const float *__restrict__ ws, int splits, int M, int N, float alpha, float beta,
+                                                           float *__restrict__ c, int ldc) {
+    __shared__ float red[16][17];
+    const int zl = threadIdx.x >> 4, il = threadIdx.x & 15;
+    const size_t tot = (size_t)M * N, i = (size_t)blockIdx.x * 16 + il;
+    float s = 0.f;
+    if (i < tot)
+        for (int z = zl; z < splits; z += 16) s += ws[(size_t)z * tot + i];
+    red[zl][il] = s;
+    __syncthreads();
+    if (zl == 0 && i < tot) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][il];
+        const size_t r = i / N, q = i - r * N;
+        float *o = c + r * ldc + q;
+        *o = alpha * t + (beta != 0.f ? beta * *o : 0.f);
+    }
+}
+
 #include "yk_gemm_f32.h"
 
 extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B,
@@ -160,8 +184,12 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
     else hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
     if (s > 1) {
         const size_t tot = (size_t)M * N;
-        hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta, C,
-                           ldc);
+        if (s >= 16 && tot <= 65536)
+            hipLaunchKernelGGL(splitk_sum16_kernel, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha,
+                               beta, C, ldc);
+        else
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta,
+                               C, ldc);
     }
     YK_HIP(hipGetLastError());
     return YK_OK;
