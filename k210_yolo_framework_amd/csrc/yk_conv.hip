@@ -1536,7 +1536,7 @@ __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
 // running out of phase; the pointwise GEMM walks N in passes of 48 columns so the accumulator stays
 // 12*TM registers; depthwise weights come from LDS.
 // -------------------------------------------------------------------------------------
-template <int TM>
+template <int TM, int NP, int KS>                                    // NP: bound of the 48-column passes (N <= 48 * NP); KS: of the k-steps (Cin <= 32 * KS)
 __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     constexpr int NT = 256, BM = 64 * TM, TN = 3;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1608,15 +1608,15 @@ __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     // LDS, which keeps the workgroup's footprint at max(inputs, outputs) instead of their sum - more workgroups per CU.
     const int nl4 = (lane >> 4) * 4;
     const bool capped_o = a.cap < 3.0e38f;
-    half8 xf[TM][4];                                                 // c0p <= 128: at most four k-steps of 32
+    half8 xf[TM][KS];                                                // c0p <= 128: at most four k-steps of 32
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < KS; ++kt)
             xf[i][kt] = *reinterpret_cast<const half8 *>(As + ((wid * TM + i) * 16 + fr) * LDA + min(kt, nk - 1) * 32 + fk);
-    half4 outv[4][TM][TN];
+    half4 outv[NP][TM][TN];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < NP; ++ps) {
         if (ps < npass) {
             floatx4 acc[TM][TN];
 #pragma unroll
@@ -1624,7 +1624,7 @@ __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < KS; ++kt) {
                 if (kt < nk) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -1656,7 +1656,7 @@ __global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
+    for (int ps = 0; ps < NP; ++ps)
         if (ps < npass)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -1679,12 +1679,21 @@ static int launch_lr(const igemm_args &a, hipStream_t st) {
     const int Kp = (a.c0p + 31) & ~31, npass = (a.N + 47) / 48;
     const size_t lds_in = ((size_t)BM * (Kp + a.lda_pad) + (size_t)9 * a.c0p + (size_t)((a.N + 15) / 16) * (Kp / 32) * 512) * 2 + (size_t)2 * npass * 48 * 4;
     const size_t lds = std::max(lds_in, (size_t)BM * (npass * 48 + 8) * 2);   // the output tile reuses the input side
-    static size_t attr_lds = 64 * 1024;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_lr_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
-    hipLaunchKernelGGL((fused_lr_kernel<TM>), dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
+    // the results of every pass and the pixel fragments of every k-step stay in registers: instantiating for the real counts (1, 2 or
+    // up to 4 each) keeps them at 12+8 / 24+16 / 48+32 registers per 16 rows instead of always the maximum, which spilled at the
+    // 5-waves-per-SIMD budget (24->48: 30.9 -> 28.9 us).  Six waves per SIMD (80 registers, one spill) measured slower: 29.5 us.
+    auto go = [&](auto kern) {
+        static size_t attr_lds = 64 * 1024;
+        if (lds > attr_lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_lds = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM), dim3(256), lds, st, a);
+    };
+    const int nk = Kp / 32;
+    if (npass <= 1 && nk <= 1) go(fused_lr_kernel<TM, 1, 1>);
+    else if (npass <= 2 && nk <= 2) go(fused_lr_kernel<TM, 2, 2>);
+    else go(fused_lr_kernel<TM, 4, 4>);
     return YK_OK;
 }
 
