@@ -1751,7 +1751,10 @@ int yk_igemm_fused_pick(const igemm_args &a) {
     static const bool lr = yk_dev_env("YK_LR") ? yk_dev_env("YK_LR")[0] != '0' : true;
     // (an LDS-DMA staged variant of this kernel was built and measured: 34.5 vs 33.0 us on the 24->48 block - these layers are bound by
     // VALU issue, ~650 vector instructions per wave of which 108 are the depthwise MACs, not by how the taps are fetched; dropped)
-    if (lr && a.c0p <= 128 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) return (a.c0p <= 48) ? LR_T2 : LR_T1;
+    if (lr && a.c0p <= 128 && a.N <= 192 && (long)a.M * a.N >= (1l << 22)) {
+        if (const char *e = yk_dev_env("YK_LR_TM")) return atoi(e) == 2 ? LR_T2 : LR_T1;            // dev sweep
+        return (a.c0p <= 32) ? LR_T2 : LR_T1;   // measured (us, 128- vs 64-pixel tile): 24 ch 28.0 / 33.0, 48 ch 23.5 / 22.3, 96 ch 28.3 / 26.2
+    }
     if (wide && 768 % G == 0 && a.c0p <= 768) {
         // aim at one or two depthwise items per thread: BM * G ~ 768..1536
         if (a.N <= 48) return WIDE_4x3_T4;                                  // BM 256
