@@ -1537,7 +1537,7 @@ __global__ void __launch_bounds__(768) fused_wide_kernel(const igemm_args a) {
 // 12*TM registers; depthwise weights come from LDS.
 // -------------------------------------------------------------------------------------
 template <int TM, int NP, int KS>                                    // NP: bound of the 48-column passes (N <= 48 * NP); KS: of the k-steps (Cin <= 32 * KS)
-__global__ void __launch_bounds__(256, 5) fused_lr_kernel(const igemm_args a) {
+__global__ void __launch_bounds__(256, (TM == 2 && NP == 4) ? 4 : 5) fused_lr_kernel(const igemm_args a) {   // <2,4,4> would spill at 5
     constexpr int NT = 256, BM = 64 * TM, TN = 3;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Cp = a.c0p, Kp = (Cp + 31) & ~31, LDA = Kp + a.lda_pad;
