@@ -128,12 +128,16 @@ class Helper(object):
 
     # ---- image side (behaviour of tools/utils.py:339-406) -----------------------------------------
     def _read_img(self, img_path: str) -> np.ndarray:
-        """RGB uint8 [H,W,3] like skimage.io.imread + gray2rgb / alpha drop (utils.py:339-355)."""
+        """RGB [H,W,3] like skimage.io.imread + gray2rgb / alpha drop (utils.py:339-355); pinned against the real skimage for every PIL
+        mode by tests/golden/imread_golden.npz."""
         from PIL import Image
         im = Image.open(img_path)
-        if im.mode not in ('RGB', 'RGBA', 'L'):          # palette, CMYK, 16-bit ...: what imread's PIL plugin converts
-            im = im.convert('RGBA' if 'A' in im.mode or 'transparency' in im.info else 'RGB')
-        img = np.asarray(im)
+        if im.mode.startswith('I;16'):                   # 16-bit gray stays uint16 (imread's PIL plugin keeps the sample depth)
+            img = np.asarray(im).astype(np.uint16)
+        else:
+            if im.mode not in ('RGB', 'RGBA', 'L'):      # palette, LA, CMYK, bilevel ...: what imread's PIL plugin converts
+                im = im.convert('RGBA' if 'A' in im.mode or 'transparency' in im.info else 'RGB')
+            img = np.asarray(im)
         if img.ndim == 2:
             img = np.repeat(img[..., None], 3, axis=-1)
         return img[..., :3]

@@ -206,3 +206,18 @@ def test_free_functions_shapes_and_values():
 
 def test_error_tag_text():
     assert ERROR == '[ ERROR ]'
+
+
+def test_read_img_equals_real_skimage_imread_for_every_pil_mode():
+    """tools/utils.py:352-355 (skimage.io.imread, gray2rgb, drop alpha).  Expected arrays were produced by the REAL scikit-image
+    (tests/golden/make_imread_golden.py); lossless files only - JPEG decoders differ between libjpeg builds."""
+    import os
+    from k210_yolo_framework_amd.helper import Helper
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    exp = np.load(os.path.join(here, 'imread_golden.npz'))
+    h = Helper.__new__(Helper)
+    assert len(exp.files) == 9
+    for name in exp.files:
+        got = h._read_img(os.path.join(here, 'imread', name))
+        assert got.dtype == exp[name].dtype and got.shape == exp[name].shape, name
+        assert np.array_equal(got, exp[name]), name
