@@ -809,7 +809,7 @@ static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
     {128, 64, 32, "igemm_128x64"}, {128, 48, 32, "igemm_128x48"}, {128, 96, 32, "igemm_128x96"},
     {128, 192, 64, "igemm_128x192k64"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 64, "igemm_128x128k64"},
     {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}, {128, 64, 64, "igemm_128x64k64"},
-    {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}};
+    {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}, {256, 128, 64, "igemm_256x128k64"}};
 
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
@@ -824,6 +824,15 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     case IGEMM_128x64K64: return launch_cfg<128, 64, 2, 2, 64, false, true>(a, st);
     case IGEMM_64x128: return launch_cfg<64, 128, 2, 2, 64, false, true>(a, st);
     case IGEMM_64x192: return launch_cfg<64, 192, 2, 2, 64, false, true>(a, st);
+#ifdef YK_DEV
+    // next step of DESIGN.md 8(1): the ring kernel on EIGHT waves (4 x 2, 64x64 per wave) - the waves per CU of the 64x128 tile with half
+    // its operand stream.  Never picked; reachable with YK_IGEMM_FORCE in the developer build, LDS-DMA preconditions only.
+    case IGEMM_256x128: {
+        const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
+        if ((a.c0p + a.c1p) % 64 || a.c0p % 64 || (uint64_t)a.in0_bytes + margin >= YK_OOB || (uint64_t)a.in1_bytes + margin >= YK_OOB) break;
+        return launch_pipe<256, 128, 4, 2, 2>(a, st);
+    }
+#endif
     }
     yk_set_error("yk_launch_igemm: bad config %d", cfg);
     return YK_ERR_ARG;
