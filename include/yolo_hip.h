@@ -133,8 +133,9 @@ int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t
  *   YK_PRECISION_F16    fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulate — the throughput mode
  *                       (= yk_plan_create).  Scores drift ~2e-4 mean / ~2e-3 max from the fp32 Keras path.
  *   YK_PRECISION_F16X2  fp32 activations in HBM, compensated fp16 MFMA operands (x = hi + lo, three MFMAs per product),
- *                       fp32 accumulate: fp32-class results (the "within 1e-3, indices exact" clause of the north star),
- *                       no fusion.  Per-image operand scaling: results never depend on the batch mates. */
+ *                       fp32 accumulate: fp32-class results (the "within 1e-3, indices exact" clause of the north star;
+ *                       measured 2e-6 of max|logit|), about 2.7x the time of the fp16 plan.  Per-image operand scaling:
+ *                       results never depend on the batch mates. */
 #define YK_PRECISION_F16 0
 #define YK_PRECISION_F16X2 1
 int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
