@@ -10,6 +10,7 @@ Cases (anchors = main.c:46-52, threshold/nms = main.c:280-287):
   l1_letterbox            : net 416x416 vs the hard-coded 320x224 image (region_layer.c:24-25)
                             -> non-identity correct_region_boxes
   l0_c1                   : single class (channels = 3*6), degenerate softmax
+  l0_empty / l1_extreme / l0_all : nothing above the threshold / logits in +-100 / threshold 0 (edge cases)
 """
 import sys
 from pathlib import Path
@@ -47,11 +48,20 @@ def main():
         'l1_typical': (20, 14, 3, 20, 1, 0.6, 0.3, (320, 224), 't'),
         'l1_letterbox': (20, 14, 3, 20, 1, 0.5, 0.45, (416, 416), 't'),
         'l0_c1': (10, 7, 3, 1, 0, 0.3, 0.3, (320, 224), 'u'),
+        # edge cases (appended: the cases above keep their random draws)
+        'l0_empty': (10, 7, 3, 20, 0, 0.6, 0.3, (320, 224), 'e'),        # nothing reaches the threshold: no box survives, no draw call
+        'l1_extreme': (20, 14, 3, 20, 1, 0.6, 0.3, (320, 224), 'x'),     # logits U(-100, 100): expf overflow / underflow / subnormals
+        'l0_all': (10, 7, 3, 20, 0, 0.0, 0.3, (320, 224), 'u'),          # threshold 0: every class of every box is a candidate
     }
     out = {}
     for name, (W, H, A, Cn, li, thr, nms, net_wh, kind) in cases.items():
         if kind == 'u':
             x = rng.uniform(-6, 6, (A, 5 + Cn, H, W)).astype(np.float32)
+        elif kind == 'e':
+            x = rng.normal(0, 1, (A, 5 + Cn, H, W)).astype(np.float32)
+            x[:, 4] = -12.0
+        elif kind == 'x':
+            x = rng.uniform(-100, 100, (A, 5 + Cn, H, W)).astype(np.float32)
         else:
             x = typical(rng, W, H, A, Cn)
         o, b, p, d = oracle.ref_region_run(x, ANCHORS[li], W, H, A, Cn, thr, nms, net_wh)
