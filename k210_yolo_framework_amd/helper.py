@@ -156,10 +156,12 @@ class Helper(object):
         if is_resize:
             scale, translation = self.letterbox_params(img.shape[:2])
             if isinstance(true_box, np.ndarray):
-                img_wh = np.array([img.shape[1], img.shape[0]])
-                in_wh = self.in_hw[0][::-1]
-                true_box[:, 1:3] = (true_box[:, 1:3] * img_wh * scale + translation) / in_wh
-                true_box[:, 3:5] = (true_box[:, 3:5] * img_wh * scale) / in_wh
+                # centre and size (fractions of the source image) -> pixels of the scaled image -> fractions of the network tensor;
+                # only the centre is shifted by the letterbox margin (utils.py:386-389)
+                src_wh, net_wh = np.tile(img.shape[1::-1], 2), np.tile(self.in_hw[0][::-1], 2)
+                moved = true_box[:, 1:5] * src_wh * np.tile(scale, 2)
+                moved[:, :2] += translation
+                true_box[:, 1:5] = moved / net_wh
             img = letterbox_bilinear(img, tuple(self.in_hw[0]), float(scale[0]), translation)
         if is_training:
             raise NotImplementedError('imgaug augmentation is out of scope (SURVEY.md §2 #6)')
@@ -196,11 +198,10 @@ class Helper(object):
 
     def set_dataset(self, batch_size, rand_seed, is_training=True, is_resize=True):
         """utils.py:443-450."""
-        self.train_dataset = self._create_dataset(self.train_list, batch_size, rand_seed, is_training, is_resize)
-        self.test_dataset = self._create_dataset(self.test_list, batch_size, rand_seed, False, is_resize)
         self.batch_size = batch_size
-        self.train_epoch_step = self.train_total_data // self.batch_size
-        self.test_epoch_step = self.test_total_data // self.batch_size
+        for split, lst, train in (('train', self.train_list, is_training), ('test', self.test_list, False)):
+            setattr(self, split + '_dataset', self._create_dataset(lst, batch_size, rand_seed, train, is_resize))
+            setattr(self, split + '_epoch_step', getattr(self, split + '_total_data') // batch_size)
 
     def get_iter(self, is_training=True):
         """utils.py:452-456: the next batch of the chosen dataset."""
