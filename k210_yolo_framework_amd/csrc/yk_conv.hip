@@ -851,7 +851,10 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
         const char *f = yk_dev_env("YK_IGEMM_FORCE");
         if (f && f[0]) {
             const int c = atoi(f);
-            if (c >= 0 && c < IGEMM_NUM && c != IGEMM_F32_64x80 && c != IGEMM_F32_128x64 && a.N % g_cfg[c].bn == 0) return c;
+            const bool ring_only = c == IGEMM_256x128;                 // has no register-staged fallback: only where the LDS-DMA ring applies
+            const bool ring_ok = ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);
+            if (c >= 0 && c < IGEMM_NUM && c != IGEMM_F32_64x80 && c != IGEMM_F32_128x64 && a.N % g_cfg[c].bn == 0 && (!ring_only || ring_ok))
+                return c;
         }
     }
     const long mt128 = (a.M + 127) / 128;
