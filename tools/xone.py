@@ -1,6 +1,7 @@
 """Dev tool: three runs of the f16x2 plan of the headline network (for rocprofv3 passes)."""
+import os
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from k210_yolo_framework_amd import engine, netspec as ns
