@@ -92,6 +92,13 @@ struct xview {
     int G, H, W;                // channel groups of 8, stored height / width
 };
 
+// acc += f16(lo | hi half of a) * w: one VALU op, fp32 accumulate, no conversion instruction
+__device__ __forceinline__ void x_fma_mix_lo(float &acc, uint32_t a, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(w));
+}
+__device__ __forceinline__ void x_fma_mix_hi(float &acc, uint32_t a, float w) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(w));
+}
 __device__ __forceinline__ void x_split(float s, yk_half &hi, yk_half &lo) {
     hi = (yk_half)s;
     lo = (yk_half)(s - (float)hi);
@@ -127,6 +134,7 @@ struct xg_args {
     yk_fastdiv fd_hw, fd_wo;
     int splitk;
     float *slab;                // split-K partial sums [z][tile][reg][thread] floatx4
+    int dbg;                    // developer builds: phase knock-out bits (tools/xbench.py), 0 in production
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -174,19 +182,12 @@ __device__ __forceinline__ void xg_prep(const xg_args &a, int b0, int bl, float 
 // epilogue: lane holds channels n..n+3 (acc regs) of GEMM row (wm*TM+i)*16 + fr
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void xg_epilogue(const xg_args &a, floatx4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int b0, int bl,
-                                            const int (&rowb)[BM / WM / 16], const float *s_up, const float *s_down,
-                                            const float *s_rup, uint32_t *s_amax) {
+                                            const int (&rowb)[BM / WM / 16], const float4 (&sc)[BN / WN / 16], const float4 (&bs)[BN / WN / 16],
+                                            const float *s_up, const float *s_down, const float *s_rup, uint32_t *s_amax) {
     typedef xg_cfg<BM, BN, WM, WN> C;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN, fr = lane & 15, nl4 = (lane >> 4) * 4;
     unsigned char *Cs = xsm;
-    float4 sc[C::TN], bs[C::TN];
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + (wn * C::TN + j) * 16 + nl4;
-        sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
-        bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
-    }
 #pragma unroll
     for (int i = 0; i < C::TM; ++i) {
         const int r = (wm * C::TM + i) * 16 + fr, m = m0 + r;
@@ -270,11 +271,19 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     const int vz = v / (gx * gy), vr = v - vz * (gx * gy), vy = vr / gx, vx = vr - vy * gx;
     const int m0 = vx * BM, n0 = vy * BN;
     const int b0 = (int)x_div((uint32_t)m0, a.fd_hw), bl = (int)x_div((uint32_t)min(a.M - 1, m0 + BM - 1), a.fd_hw);
+    // BatchNorm scale / bias of this lane's channels: requested first, used last (the epilogue would otherwise open with a cold miss)
+    float4 sc[TN], bs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 16 + (lane >> 4) * 4;
+        sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
+        bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+    }
 
     // K range of this split: steps [kt0, kt0 + nk) of the walk  seg 0: tap-major over s0   |   seg 1: tap-major over s1
     const int kb = a.taps * a.nc0, nk_all = kb + a.taps * a.nc1;
     const int per = (nk_all + a.splitk - 1) / a.splitk;
-    const int kt0 = vz * per, nk = max(0, min(per, nk_all - kt0));
+    const int kt0 = vz * per, nk = (a.dbg & 1) ? 0 : max(0, min(per, nk_all - kt0));
     const int lim = kt0 + nk;
 
     // ---- this lane's A rows (fixed over the walk): row l>>2 of the 16-row blocks wid*AR + it, fetching chunk (l&3) ^ ((row>>1)&3)
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) dma(s);                       // steps past `lim` deposit zeros and keep the vmcnt arithmetic uniform
-    xg_prep<BM, NW>(a, b0, bl, s_up, s_resc, s_down, s_rup, s_amax);   // slot loads fly with the prologue DMAs
+    if (!(a.dbg & 2)) xg_prep<BM, NW>(a, b0, bl, s_up, s_resc, s_down, s_rup, s_amax);   // slot loads fly with the prologue DMAs
     bool in0 = a.nc1 > 0 && kt0 < kb;                               // accumulators still in src0's units
     auto rescale = [&]() {
 #pragma unroll
@@ -436,7 +445,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
             in0 = false;
         }
         dma(wr);
-        compute(rd);
+        if (!(a.dbg & 16)) compute(rd);
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
@@ -452,7 +461,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) mine[(i * TN + j) * C::NT] = acc[i][j];
     } else {
-        xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, s_up, s_down, s_rup, s_amax);
+        if (!(a.dbg & 4)) xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, sc, bs, s_up, s_down, s_rup, s_amax);
     }
 }
 
@@ -469,6 +478,14 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_reduce_kernel(const xg_args a
     const int vy = v / gx, vx = v - vy * gx;
     const int m0 = vx * BM, n0 = vy * BN;
     const int b0 = (int)x_div((uint32_t)m0, a.fd_hw), bl = (int)x_div((uint32_t)min(a.M - 1, m0 + BM - 1), a.fd_hw);
+    // BatchNorm scale / bias of this lane's channels: requested first, used last (the epilogue would otherwise open with a cold miss)
+    float4 sc[TN], bs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + ((wid % WN) * TN + j) * 16 + (lane >> 4) * 4;
+        sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
+        bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+    }
     xg_prep<BM, C::NW>(a, b0, bl, s_up, s_resc, s_down, s_rup, s_amax);
     int rowb[TM];
 #pragma unroll
@@ -487,13 +504,19 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_reduce_kernel(const xg_args a
             for (int j = 0; j < TN; ++j) acc[i][j] += __builtin_nontemporal_load(src + (i * TN + j) * C::NT);
     }
     __syncthreads();
-    xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, s_up, s_down, s_rup, s_amax);
+    xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, sc, bs, s_up, s_down, s_rup, s_amax);
 }
 
 // =====================================================================================================================
-// xdw_kernel: DepthwiseConv2D 3x3 + BN + activation, fp32 on the VALU.  One thread = one output pixel x 8 channels: nine taps of
-// (hi x8 | lo x8) by raw buffer loads (out-of-image taps get an out-of-range offset and arrive as zeros: Keras zero padding without
-// branches), x = hi + lo is exact in fp32, weights [9][Cp] + scale + bias from LDS.  grid (pixel groups of one image, image).
+// xdw_kernel: DepthwiseConv2D 3x3 + BN + activation, fp32 on the VALU, input PATCH staged by LDS-DMA.
+// A workgroup owns TH x TW output pixels x GS channel groups of one image.  Its input patch ((TH-1)s+3 rows x (TW-1)s+3 columns x GS
+// groups) arrives in ONE burst of `buffer_load ... lds`: every lane computes the source address of the 16 bytes that belong at its
+// linear LDS position (hi halves in one region, lo halves in another, so a tap read is a conflict-free ds_read_b128); pixels
+// outside the image get an out-of-range offset and arrive as zeros - Keras zero padding costs nothing.  A thread keeps ONE channel
+// group for all of its pixels (blockDim is a multiple of GS), so the nine tap weights, scale and bias of its eight channels live in
+// registers, fetched while the patch is in flight.  (Round 3, first version: one thread = one output pixel, taps by buffer loads,
+// the whole [11][C] parameter table copied to LDS by every workgroup - at 384 channels that copy was most of the kernel: 16 us for
+// 27.5 MB.)
 // =====================================================================================================================
 struct xdw_args {
     xview in;
@@ -503,16 +526,53 @@ struct xdw_args {
     uint8_t *out;
     int *eexp_out;
     uint32_t *amax_out;
-    yk_fastdiv fd_g, fd_wo;            // division by G and Wo
+    // geometry, fixed at plan creation
+    int TH, TW, PH, PW, GS, gsl, tiles_x, tiles_y, NT, n16, n16p;
+    int dbg;
+    yk_fastdiv fd_gsl, fd_tpi, fd_tx, fd_gs, fd_pw, fd_tw;
 };
 __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
-    float *par = reinterpret_cast<float *>(xsm);
     __shared__ uint32_t smax;
     __shared__ float sf[2];
-    const int tid = threadIdx.x, b = blockIdx.y, G = a.in.G, Cp = G * 8;
-    for (int i = tid; i < 11 * Cp / 4; i += 256) reinterpret_cast<float4 *>(par)[i] = reinterpret_cast<const float4 *>(a.par)[i];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, G = a.in.G, Cp = G * 8, s = a.stride;
+    unsigned char *HI = xsm, *LO = xsm + (size_t)a.n16p * 16;
+    // block -> (image, tile, group slice)
+    const uint32_t bid = blockIdx.x;
+    const uint32_t tl_all = x_div(bid, a.fd_gsl), gsi = bid - tl_all * a.gsl;
+    const uint32_t b = x_div(tl_all, a.fd_tpi), tl = tl_all - b * (a.tiles_x * a.tiles_y);
+    const uint32_t ty = x_div(tl, a.fd_tx), tx = tl - ty * a.tiles_x;
+    const int oy0 = (int)ty * a.TH, ox0 = (int)tx * a.TW, g0 = (int)gsi * a.GS;
+    const int iy0 = oy0 * s - a.pad_t, ix0 = ox0 * s - a.pad_l;
+    // (1) the patch, by DMA (full waves only: an inactive lane would leave its 16 bytes unwritten)
+    {
+        const uint32_t img = (uint32_t)a.in.H * a.in.W * G * 32u;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in.p + (size_t)b * img), 0, img, 0x00020000);
+        const int nwf = a.NT >> 6;
+        if (wid < nwf && !(a.dbg & 1))
+            for (int q0 = wid * 64; q0 < a.n16p; q0 += nwf * 64) {
+                const uint32_t q = q0 + lane;
+                const uint32_t pos = x_div(q, a.fd_gs), g = q - pos * a.GS;
+                const uint32_t r = x_div(pos, a.fd_pw), c = pos - r * a.PW;
+                const int iy = iy0 + (int)r, ix = ix0 + (int)c;
+                const bool ok = (int)q < a.n16 && (unsigned)iy < (unsigned)a.in.H && (unsigned)ix < (unsigned)a.in.W;
+                const uint32_t oh = ok ? (uint32_t)(((iy * a.in.W + ix) * G + g0 + (int)g) * 32) : X_OOB, ol = oh + 16u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(HI + (size_t)q0 * 16), 16, oh, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(LO + (size_t)q0 * 16), 16, ol, 0, 0, 0);
+            }
+    }
+    // (2) this thread's channel group: weights, scale, bias -> registers (in flight with the patch)
+    const int gl = tid % a.GS, p0 = tid / a.GS, PP = a.NT / a.GS;
+    const float *wp = a.par + (size_t)(g0 + gl) * 8;
+    float4 w0[9], w1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        w0[t] = *reinterpret_cast<const float4 *>(wp + (size_t)t * Cp);
+        w1[t] = *reinterpret_cast<const float4 *>(wp + (size_t)t * Cp + 4);
+    }
+    const float4 sc0 = *reinterpret_cast<const float4 *>(wp + (size_t)9 * Cp), sc1 = *reinterpret_cast<const float4 *>(wp + (size_t)9 * Cp + 4);
+    const float4 bs0 = *reinterpret_cast<const float4 *>(wp + (size_t)10 * Cp), bs1 = *reinterpret_cast<const float4 *>(wp + (size_t)10 * Cp + 4);
     if (tid < 64) {
-        const float bound = fminf(a.cap, a.gain * x_amax_wave(a.in.amax, b) + a.off);
+        const float bound = fminf(a.cap, a.gain * x_amax_wave(a.in.amax, (int)b) + a.off);
         const int eo = x_exp_of(__float_as_uint(bound));
         if (tid == 0) {
             smax = 0u;
@@ -521,57 +581,88 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
             a.eexp_out[b] = eo;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const uint32_t idx = blockIdx.x * 256 + tid;
+    const float up = sf[0], down = sf[1];
+    const float sc[8] = {sc0.x * up, sc0.y * up, sc0.z * up, sc0.w * up, sc1.x * up, sc1.y * up, sc1.z * up, sc1.w * up};
+    const float bs[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};
     float mx = 0.f;
-    if (idx < (uint32_t)(a.Ho * a.Wo * G)) {
-        const uint32_t pix = x_div(idx, a.fd_g), g = idx - pix * G;
-        const uint32_t oy = x_div(pix, a.fd_wo), ox = pix - oy * a.Wo;
-        const int iy0 = (int)oy * a.stride - a.pad_t, ix0 = (int)ox * a.stride - a.pad_l;
-        const uint32_t img = (uint32_t)a.in.H * a.in.W * G * 32u;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in.p + (size_t)b * img), 0, img, 0x00020000);
-        uint32_t ro[3], co[3];
+    if (tid < a.NT && !(a.dbg & 2))
+        for (int p = p0; p < a.TH * a.TW; p += PP) {
+            const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const int base = ((py * s) * a.PW + px * s) * a.GS + gl;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            ro[k] = ((unsigned)(iy0 + k) < (unsigned)a.in.H) ? (uint32_t)(iy0 + k) * (a.in.W * G * 32u) + g * 32u : X_OOB;
-            co[k] = ((unsigned)(ix0 + k) < (unsigned)a.in.W) ? (uint32_t)(ix0 + k) * (G * 32u) : X_OOB;
+            for (int t = 0; t < 9; ++t) {
+                const int at = (base + ((t / 3) * a.PW + (t % 3)) * a.GS) * 16;
+                const half8 h = *reinterpret_cast<const half8 *>(HI + at), l = *reinterpret_cast<const half8 *>(LO + at);
+                const float w[8] = {w0[t].x, w0[t].y, w0[t].z, w0[t].w, w1[t].x, w1[t].y, w1[t].z, w1[t].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)h[j] + (float)l[j], w[j], acc[j]);
+            }
+            half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = x_actf(acc[j] * sc[j] + bs[j], a.slope, a.cap);
+                mx = fmaxf(mx, fabsf(v));
+                yk_half h, l;
+                x_split(v * down, h, l);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            uint8_t *o = a.out + ((((size_t)b * a.Ho + oy) * a.Wo + ox) * G + g0 + gl) * 32;
+            if (a.dbg & 4) continue;
+            *reinterpret_cast<half8 *>(o) = hi;
+            *reinterpret_cast<half8 *>(o + 16) = lo;
         }
-        u32x4 xh[9], xl[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const uint32_t o = ro[t / 3] + co[t % 3];
-            xh[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
-            xl[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16u, 0, 0);
-        }
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float4 w0 = *reinterpret_cast<const float4 *>(par + t * Cp + g * 8), w1 = *reinterpret_cast<const float4 *>(par + t * Cp + g * 8 + 4);
-            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const half8 h = __builtin_bit_cast(half8, xh[t]), l = __builtin_bit_cast(half8, xl[t]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)h[j] + (float)l[j], w[j], acc[j]);
-        }
-        const float up = sf[0], down = sf[1];
-        const float *sc = par + 9 * Cp + g * 8, *bs = par + 10 * Cp + g * 8;
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = x_actf(acc[j] * up * sc[j] + bs[j], a.slope, a.cap);
-            mx = fmaxf(mx, fabsf(v));
-            yk_half h, l;
-            x_split(v * down, h, l);
-            hi[j] = h;
-            lo[j] = l;
-        }
-        uint8_t *o = a.out + (((size_t)b * a.Ho * a.Wo + pix) * G + g) * 32;
-        *reinterpret_cast<half8 *>(o) = hi;
-        *reinterpret_cast<half8 *>(o + 16) = lo;
-    }
     x_amax_lds(&smax, 0, mx);
     __syncthreads();
     if (tid == 0 && smax) x_amax_global(a.amax_out + (size_t)b * XS, smax);
 }
+// patch geometry of a depthwise layer: fewest bytes moved per output (halo) among the shapes that leave the chip at least ~2
+// workgroups per CU, with the patch under 40 KB (3+ workgroups per CU)
+void xdw_geometry(xdw_args &d, int max_batch) {
+    const int G = d.in.G, s = d.stride;
+    double best = -1.0;
+    const long lds_cap = (yk_dev_env("YK_X_DWLDS") ? atoi(yk_dev_env("YK_X_DWLDS")) : 40) * 1024L;
+    const double gs_pref = yk_dev_env("YK_X_DWGS") ? atof(yk_dev_env("YK_X_DWGS")) : 3.0;
+    for (int GS = 1; GS <= std::min(G, 64); ++GS) {
+        if (G % GS) continue;
+        const int NT = 256 / GS * GS;
+        if (NT < 128) continue;
+        for (int TH = 1; TH <= d.Ho; ++TH)
+            for (int TW = 1; TW <= d.Wo; ++TW) {
+                if (TW != d.Wo && (TW & 3)) continue;
+                const int PH = (TH - 1) * s + 3, PW = (TW - 1) * s + 3;
+                const long n16 = (long)PH * PW * GS;
+                if (n16 * 32 > lds_cap) continue;
+                const long tiles = (long)((d.Ho + TH - 1) / TH) * ((d.Wo + TW - 1) / TW), wgs = tiles * (G / GS) * max_batch;
+                const double cover = (double)d.Ho * d.Wo / ((double)tiles * TH * TW);        // ragged tiles waste threads
+                const double halo = (double)TH * TW * s * s / ((double)PH * PW);             // bytes used / bytes staged
+                const double items = (double)TH * TW * GS / NT;                              // pixels per thread
+                double score = halo * cover * std::min(1.0, items / 4.0) * std::min(1.0, wgs / 512.0) * std::min(1.0, GS / gs_pref);
+                if (score > best) {
+                    best = score;
+                    d.TH = TH; d.TW = TW; d.PH = PH; d.PW = PW; d.GS = GS; d.NT = NT;
+                    d.gsl = G / GS;
+                    d.tiles_x = (d.Wo + TW - 1) / TW;
+                    d.tiles_y = (d.Ho + TH - 1) / TH;
+                    d.n16 = (int)n16;
+                    d.n16p = (int)((n16 + 63) & ~63L);
+                }
+            }
+    }
+    d.fd_gsl = yk_make_fastdiv((uint32_t)d.gsl);
+    d.fd_tpi = yk_make_fastdiv((uint32_t)(d.tiles_x * d.tiles_y));
+    d.fd_tx = yk_make_fastdiv((uint32_t)d.tiles_x);
+    d.fd_gs = yk_make_fastdiv((uint32_t)d.GS);
+    d.fd_pw = yk_make_fastdiv((uint32_t)d.PW);
+    d.fd_tw = yk_make_fastdiv((uint32_t)d.TW);
+}
+
+#include "yk_xblock.h"
 
 // =====================================================================================================================
 // stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once.
@@ -784,7 +875,7 @@ float x_h2f(uint16_t u) {
     return (float)h;
 }
 
-enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX };
+enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK };
 enum { XT_REAL = 0, XT_UP = 1, XT_CAT = 2 };
 // tile configurations of xg_kernel
 enum { XC_64x64 = 0, XC_64x128, XC_128x64, XC_128x128, XC_NUM };
@@ -808,6 +899,8 @@ struct xlaunch {
     xstem_args s;
     xpool_args p;
     xadd_args ad;
+    xb_args b;
+    int tm = 0, tn = 0;                // xb_kernel<tm, tn>
     int Ho = 0, Wo = 0;
     int cfg = 0, ns = 2;               // xg_kernel tile configuration and ring depth
     unsigned lds = 0;
@@ -858,6 +951,96 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
     }
     yk_set_error("f16x2: bad tile configuration %d", cfg);
     return YK_ERR_ARG;
+}
+
+template <int TM, int TN>
+int x_launch_b(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+    static unsigned allowed = 64 * 1024;
+    if (lds > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        allowed = 160 * 1024;
+    }
+    dim3 grid((unsigned)(batch * g.tiles_x * g.tiles_y), (unsigned)((g.N + 64 * TN - 1) / (64 * TN)));
+    hipLaunchKernelGGL((xb_kernel<TM, TN>), grid, dim3(256), lds, st, g);
+    return YK_OK;
+}
+const int g_xb_tm[] = {2, 3, 4, 5, 8}, g_xb_tn[] = {1, 2, 3, 6};
+bool xb_has(int tm, int tn) {
+    if (tm * tn > 24) return false;
+    bool a = false, b = false;
+    for (int v : g_xb_tm) a |= v == tm;
+    for (int v : g_xb_tn) b |= v == tn;
+    return a && b;
+}
+int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+#define XB_CASE(M, N) \
+    if (tm == M && tn == N) return x_launch_b<M, N>(g, batch, lds, st);
+    XB_CASE(2, 1) XB_CASE(2, 2) XB_CASE(2, 3) XB_CASE(2, 6)
+    XB_CASE(3, 1) XB_CASE(3, 2) XB_CASE(3, 3) XB_CASE(3, 6)
+    XB_CASE(4, 1) XB_CASE(4, 2) XB_CASE(4, 3) XB_CASE(4, 6)
+    XB_CASE(5, 1) XB_CASE(5, 2) XB_CASE(5, 3)
+    XB_CASE(8, 1) XB_CASE(8, 2) XB_CASE(8, 3)
+#undef XB_CASE
+    yk_set_error("f16x2: no fused block kernel <%d,%d>", tm, tn);
+    return YK_ERR_ARG;
+}
+unsigned xb_lds(int tm, int tn, int n16p) {
+    const int bm = 16 * tm, bn = 64 * tn;
+    const int ipp = (tn >= 3 && tm >= 2) ? (tm + 1) / 2 : tm;
+    const int ring = n16p * 32 + 2048 + bn * 128 + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
+    return (unsigned)(std::max(ring, ct) + 64);
+}
+// tile geometry of a fused block for max_batch images, by a small cost model (cycles).  Per step a workgroup spends a depthwise pass
+// of its 256 threads over BM*4 items (~700 cycles each round) and TM*TN*3 MFMAs per wave, plus the exposed part of the step's DMA; a
+// fixed prologue / epilogue; co-resident workgroups (LDS permitting) overlap each other's phases partly.  The whole N in one
+// workgroup is preferred (an N split repeats the depthwise work).  Returns false when nothing fits (the caller then keeps the
+// two-launch form).
+bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int max_batch) {
+    const int s = g.stride;
+    double best = -1.0;
+    const int force_tm = yk_dev_env("YK_XB_TM") ? atoi(yk_dev_env("YK_XB_TM")) : 0, force_tn = yk_dev_env("YK_XB_TN") ? atoi(yk_dev_env("YK_XB_TN")) : 0;
+    const int force_tw = yk_dev_env("YK_XB_TW") ? atoi(yk_dev_env("YK_XB_TW")) : 0;
+    for (int tm : g_xb_tm)
+        for (int tn : g_xb_tn) {
+            if (!xb_has(tm, tn) || (force_tm && tm != force_tm) || (force_tn && tn != force_tn)) continue;
+            const int bm = 16 * tm, bn = 64 * tn;
+            if (bn - 63 > ((g.N + 15) & ~15) && tn != 1) continue;      // wider than the layer
+            const int nsl = (g.N + bn - 1) / bn;
+            for (int TW = 1; TW <= std::min(g.Wo, bm); ++TW) {
+                if (force_tw && TW != force_tw) continue;
+                const int TH = std::min(g.Ho, bm / TW);
+                if (TH * TW <= 16 * (tm - 1)) continue;                 // would leave a whole row block empty
+                const int PH = (TH - 1) * s + 3, PW = (TW - 1) * s + 3;
+                const int n16 = PH * PW * 4, n16p = (n16 + 63) & ~63;
+                if (n16p > 1536) continue;
+                const unsigned lds = xb_lds(tm, tn, n16p);
+                if (lds > 160 * 1024) continue;
+                const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
+                const long wgs = tiles * nsl * max_batch;
+                const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
+                const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / lds)));
+                const long conc = std::max(1L, std::min<long>(per_cu, (wgs + 255) / 256));
+                const long rounds = (wgs + 256 * conc - 1) / (256 * conc);
+                const double t_dw = ((bm * 4 + 255) / 256) * 700.0, t_mma = tm * tn * 48.0;
+                const double bytes = n16p * 32.0 + 2048 + bn * 128.0;
+                const double t_step = t_dw + t_mma + bytes / 64.0 + 400.0;
+                const double t_wg = g.nk * t_step + 6000.0 + (double)bm * bn * 4 / 24.0;
+                const double cost = rounds * t_wg * (1.0 + 0.45 * (conc - 1)) / (0.5 + 0.5 * cover);
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    *tm_out = tm; *tn_out = tn; *lds_out = lds;
+                    g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p;
+                    g.tiles_x = (g.Wo + TW - 1) / TW;
+                    g.tiles_y = (g.Ho + TH - 1) / TH;
+                }
+            }
+        }
+    if (best < 0) return false;
+    g.fd_tpi = yk_make_fastdiv((uint32_t)(g.tiles_x * g.tiles_y));
+    g.fd_tx = yk_make_fastdiv((uint32_t)g.tiles_x);
+    g.fd_tw = yk_make_fastdiv((uint32_t)g.TW);
+    g.fd_pw = yk_make_fastdiv((uint32_t)g.PW);
+    return true;
 }
 
 }   // namespace
@@ -954,9 +1137,39 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             }
         }
     }
+    // DepthwiseConv2D(3x3) whose only consumer is the next op, a 1x1 stride-1 Conv2D: one launch (yk_xblock.h), the depthwise
+    // tensor is never allocated.  The tile geometry is chosen here, for max_batch.
+    struct xfuse {
+        xb_args g;
+        int tm = 0, tn = 0;
+        unsigned lds = 0;
+    };
+    std::vector<int> dw_of(n_ops, -1);
+    std::vector<xfuse> fuse(n_ops);
+    std::vector<char> gone(n_tensors, 0);
+    if (!yk_dev_env("YK_X_NOFUSE"))
+        for (int i = 0; i + 1 < n_ops; ++i) {
+            const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
+            const int y = o[YK_F_OUT];
+            if (o[YK_F_TYPE] != YK_OP_DWCONV || q[YK_F_TYPE] != YK_OP_CONV || q[YK_F_K] != 1 || q[YK_F_STRIDE] != 1 || q[YK_F_IN0] != y ||
+                p->T[y].uses != 1 || p->T[y].kind != XT_REAL || p->T[o[YK_F_IN0]].kind != XT_REAL || p->T[o[YK_F_IN0]].is_input ||
+                (q[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT))
+                continue;
+            xfuse &f = fuse[i + 1];
+            memset(&f.g, 0, sizeof(f.g));
+            f.g.Ho = p->T[y].h;
+            f.g.Wo = p->T[y].w;
+            f.g.N = q[YK_F_COUT];
+            f.g.stride = o[YK_F_STRIDE];
+            f.g.nk = ((p->T[y].cp >> 3) + 3) / 4;
+            if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch)) continue;
+            dw_of[i + 1] = i;
+            skip[i] = 1;
+            gone[y] = 1;
+        }
     for (int i = 1; i < n_tensors; ++i) {
         xtens &t = p->T[i];
-        if (t.kind != XT_REAL) continue;
+        if (t.kind != XT_REAL || gone[i]) continue;
         bool folded = false;
         for (int k = 0; k < n_ops; ++k)
             if (ops[(size_t)k * YK_OP_FIELDS + YK_F_OUT] == i && add_of[k] >= 0) folded = true;
@@ -988,6 +1201,76 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         v.H = t.h;
         v.W = t.w;
         return v;
+    };
+    // conv weights -> device, split and tile-ordered: w * 2^s = hi + lo with max |w * 2^s| in [2^13, 2^14); [step][16-row block][hi|lo][16][32],
+    // the 16-byte chunk c of row r stored at position c ^ ((r >> 1) & 3); K walk: segment-major (source 0, then source 1), tap, channel.
+    // Also returns the per-source gains max_n |scale_n| * sum_k |w_nk| and max |bias| for the output bound.
+    auto pack_w = [&](const int32_t *o, int c0, int nc0, int nc1, int taps, int nslab, const uint8_t **dw, uint32_t *dbytes, const float **dscale,
+                      const float **dbias, float *gain0, float *gain1, float *off) -> int {
+        const int co = o[YK_F_COUT], cin = o[YK_F_CIN];
+        const int nsteps = taps * (nc0 + nc1);
+        float wmax = 0.f;
+        const size_t nw = (size_t)co * taps * cin;
+        for (size_t k = 0; k < nw; ++k) wmax = std::max(wmax, fabsf(blob[o[YK_F_W_OFF] + k]));
+        const int sexp = (wmax > 0.f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+        std::vector<uint16_t> wt((size_t)nsteps * nslab * 1024, 0);
+        std::vector<double> sum0(co, 0.0), sum1(co, 0.0);
+        for (int n = 0; n < co; ++n)
+            for (int t = 0; t < taps; ++t)
+                for (int c = 0; c < cin; ++c) {
+                    const float wv = blob[o[YK_F_W_OFF] + ((size_t)n * taps + t) * cin + c];
+                    const bool second = c >= c0;
+                    const int cc = second ? c - c0 : c;
+                    const int step = second ? taps * nc0 + t * nc1 + cc / 32 : t * nc0 + cc / 32;
+                    const int k32 = cc % 32, chunk = k32 >> 3, e = k32 & 7, r = n & 15, pos = chunk ^ ((r >> 1) & 3);
+                    const float v = ldexpf(wv, sexp);
+                    const uint16_t hi = x_f2h(v);
+                    const size_t at = ((size_t)step * nslab + (n >> 4)) * 1024 + (size_t)r * 32 + pos * 8 + e;
+                    wt[at] = hi;
+                    wt[at + 512] = x_f2h(v - x_h2f(hi));
+                    (second ? sum1 : sum0)[n] += fabs((double)wv);
+                }
+        void *d1;
+        int rc2 = x_upload(p, &d1, wt.data(), wt.size() * 2);
+        if (rc2) return rc2;
+        *dw = (const uint8_t *)d1;
+        *dbytes = (uint32_t)(wt.size() * 2);
+        *gain0 = *gain1 = *off = 0.f;
+        for (int n = 0; n < co; ++n) {
+            const float sc = fabsf(blob[o[YK_F_SCALE_OFF] + n]);
+            *gain0 = std::max(*gain0, (float)(sc * sum0[n]));
+            *gain1 = std::max(*gain1, (float)(sc * sum1[n]));
+            *off = std::max(*off, fabsf(blob[o[YK_F_BIAS_OFF] + n]));
+        }
+        *gain0 *= 1.0001f;
+        *gain1 *= 1.0001f;
+        *off *= 1.0001f;
+        if ((rc2 = x_upload_f(p, blob + o[YK_F_SCALE_OFF], co, ldexpf(1.f, -sexp), dscale))) return rc2;
+        return x_upload_f(p, blob + o[YK_F_BIAS_OFF], co, 1.f, dbias);
+    };
+    // [11][cp] depthwise parameters (nine taps, BN scale, BN bias) -> device; bound of the output from the input's max
+    auto pack_dw = [&](const int32_t *o, int c, int cp, const float **dpar, float *gain, float *off) -> int {
+        std::vector<float> par((size_t)11 * cp, 0.f);
+        *gain = *off = 0.f;
+        for (int k = 0; k < c; ++k) {
+            float sw = 0.f;
+            for (int t = 0; t < 9; ++t) {
+                const float w = blob[o[YK_F_W_OFF] + (size_t)t * c + k];
+                par[(size_t)t * cp + k] = w;
+                sw += fabsf(w);
+            }
+            const float sc = blob[o[YK_F_SCALE_OFF] + k], bs = blob[o[YK_F_BIAS_OFF] + k];
+            par[(size_t)9 * cp + k] = sc;
+            par[(size_t)10 * cp + k] = bs;
+            *gain = std::max(*gain, fabsf(sc) * sw);
+            *off = std::max(*off, fabsf(bs));
+        }
+        *gain *= 1.0001f;
+        *off *= 1.0001f;
+        void *dp;
+        int rc2 = x_upload(p, &dp, par.data(), par.size() * sizeof(float));
+        *dpar = (const float *)dp;
+        return rc2;
     };
     {
         xlaunch l;
@@ -1048,6 +1331,50 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             snprintf(nm, sizeof nm, "x:stem3x3s%d_%d", s.stride, co);
             l.flops = 2.0 * Y.h * Y.w * 27 * co;
             l.bytes = (double)X.h * X.w * 3 * 4 + (double)Y.h * Y.w * co * 4;
+        } else if (ty == YK_OP_CONV && dw_of[i] >= 0) {
+            const int32_t *dwo = ops + (size_t)dw_of[i] * YK_OP_FIELDS;
+            const int sid = dwo[YK_F_IN0];
+            const xtens &S = p->T[sid];
+            l.kind = XK_BLOCK;
+            l.tm = fuse[i].tm;
+            l.tn = fuse[i].tn;
+            l.lds = fuse[i].lds;
+            xb_args &g = l.b;
+            g = fuse[i].g;
+            const int co = o[YK_F_COUT], cin = o[YK_F_CIN];
+            float dalpha, g1, dwgain, dwoff;
+            memcpy(&dalpha, &dwo[YK_F_ALPHA], 4);
+            g.in = view_of(sid);
+            g.pad_t = dwo[YK_F_PAD_T];
+            g.pad_l = dwo[YK_F_PAD_L];
+            if ((rc = pack_dw(dwo, S.c, S.cp, &g.par, &dwgain, &dwoff))) return fail(rc);
+            yk_act_params(dwo[YK_F_ACT], dalpha, &g.dw_slope, &g.dw_cap);
+            g.dw_gain = dwgain;
+            g.dw_off = dwoff;
+            const int BN = 64 * l.tn;
+            g.nslab = ((co + BN - 1) / BN) * (BN / 16);
+            if ((rc = pack_w(o, cin, g.nk, 0, 1, g.nslab, &g.w, &g.w_bytes, &g.scale, &g.bias, &g.gain, &g1, &g.off))) return fail(rc);
+            yk_act_params(o[YK_F_ACT], alpha, &g.slope, &g.cap);
+            xtens *dst = &Y;
+            int dst_id = yid;
+            if (add_of[i] >= 0) {
+                const int32_t *q = ops + (size_t)add_of[i] * YK_OP_FIELDS;
+                const int other = (q[YK_F_IN0] == yid) ? q[YK_F_IN1] : q[YK_F_IN0];
+                g.res = view_of(other);
+                dst_id = q[YK_F_OUT];
+                dst = &p->T[dst_id];
+            }
+            g.out = dst->d;
+            g.outG = dst->cp >> 3;
+            g.eexp_out = eexp_of(dst_id);
+            g.amax_out = amax_of(dst_id);
+            if (!g.out) {
+                yk_set_error("op %d: output tensor not allocated", i);
+                return fail(YK_ERR_UNSUPPORTED);
+            }
+            snprintf(nm, sizeof nm, "x:dw3x3s%d+conv1x1_%dto%d%s[%dx%dpx,%dch]", g.stride, cin, co, g.res.p ? "+add" : "", g.TH, g.TW, 64 * l.tn);
+            l.flops = 2.0 * Y.h * Y.w * (double)cin * co + 2.0 * Y.h * Y.w * 9 * cin;
+            l.bytes = ((double)S.h * S.w * S.c + (double)Y.h * Y.w * co) * 4;
         } else if (ty == YK_OP_CONV) {
             l.kind = XK_CONV;
             xg_args &g = l.c;
@@ -1102,7 +1429,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                     tiles = ((Mmax + g_xc[cfg].bm - 1) / g_xc[cfg].bm) * ((co + g_xc[cfg].bn - 1) / g_xc[cfg].bn);
                 }
                 l.cfg = cfg;
-                l.ns = nsteps >= 3 ? 3 : 2;
+                l.ns = nsteps >= 8 ? 3 : 2;                              // measured: 2 stages win up to K = 192, 3 from 384 on
                 if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 long sk = 1;
                 if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(8, (640 + tiles - 1) / tiles), nsteps / 8);
@@ -1117,44 +1444,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             }
             const int BN = g_xc[l.cfg].bn;
             g.nslab = ((co + BN - 1) / BN) * (BN / 16);
-            // weight split: w * 2^s = hi + lo with max |w * 2^s| in [2^13, 2^14); tile order [step][16-row block][hi|lo][16][32],
-            // the 16-byte chunk c of row r stored at position c ^ ((r >> 1) & 3); K walk: segment-major, tap, channel
-            float wmax = 0.f;
-            const size_t nw = (size_t)co * ks * ks * cin;
-            for (size_t k = 0; k < nw; ++k) wmax = std::max(wmax, fabsf(blob[o[YK_F_W_OFF] + k]));
-            const int sexp = (wmax > 0.f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
-            std::vector<uint16_t> wt((size_t)nsteps * g.nslab * 1024, 0);
-            std::vector<double> sum0(co, 0.0), sum1(co, 0.0);
-            for (int n = 0; n < co; ++n)
-                for (int t = 0; t < g.taps; ++t)
-                    for (int c = 0; c < cin; ++c) {
-                        const float wv = blob[o[YK_F_W_OFF] + ((size_t)n * g.taps + t) * cin + c];
-                        const bool second = c >= c0;
-                        const int cc = second ? c - c0 : c;
-                        const int step = second ? g.taps * g.nc0 + t * g.nc1 + cc / 32 : t * g.nc0 + cc / 32;
-                        const int k32 = cc % 32, chunk = k32 >> 3, e = k32 & 7, r = n & 15, pos = chunk ^ ((r >> 1) & 3);
-                        const float v = ldexpf(wv, sexp);
-                        const uint16_t hi = x_f2h(v);
-                        const size_t at = ((size_t)step * g.nslab + (n >> 4)) * 1024 + (size_t)r * 32 + pos * 8 + e;
-                        wt[at] = hi;
-                        wt[at + 512] = x_f2h(v - x_h2f(hi));
-                        (second ? sum1 : sum0)[n] += fabs((double)wv);
-                    }
-            void *d1;
-            if ((rc = x_upload(p, &d1, wt.data(), wt.size() * 2))) return fail(rc);
-            g.w = (const uint8_t *)d1;
-            g.w_bytes = (uint32_t)(wt.size() * 2);
-            for (int n = 0; n < co; ++n) {
-                const float sc = fabsf(blob[o[YK_F_SCALE_OFF] + n]);
-                g.gain0 = std::max(g.gain0, (float)(sc * sum0[n]));
-                g.gain1 = std::max(g.gain1, (float)(sc * sum1[n]));
-                g.off = std::max(g.off, fabsf(blob[o[YK_F_BIAS_OFF] + n]));
-            }
-            g.gain0 *= 1.0001f;
-            g.gain1 *= 1.0001f;
-            g.off *= 1.0001f;
-            if ((rc = x_upload_f(p, blob + o[YK_F_SCALE_OFF], co, ldexpf(1.f, -sexp), &g.scale))) return fail(rc);
-            if ((rc = x_upload_f(p, blob + o[YK_F_BIAS_OFF], co, 1.f, &g.bias))) return fail(rc);
+            if ((rc = pack_w(o, c0, g.nc0, g.nc1, g.taps, g.nslab, &g.w, &g.w_bytes, &g.scale, &g.bias, &g.gain0, &g.gain1, &g.off))) return fail(rc);
             yk_act_params(o[YK_F_ACT], alpha, &g.slope, &g.cap);
             g.fd_hw = yk_make_fastdiv((uint32_t)(Y.h * Y.w));
             g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
@@ -1198,38 +1488,20 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             xdw_args &d = l.d;
             memset(&d, 0, sizeof(d));
             const int c = X.c, cp = X.cp;
-            // [11][cp]: nine taps, BN scale, BN bias; bound of the output from the input's max
-            std::vector<float> par((size_t)11 * cp, 0.f);
-            float gain = 0.f, off = 0.f;
-            for (int k = 0; k < c; ++k) {
-                float sw = 0.f;
-                for (int t = 0; t < 9; ++t) {
-                    const float w = blob[o[YK_F_W_OFF] + (size_t)t * c + k];
-                    par[(size_t)t * cp + k] = w;
-                    sw += fabsf(w);
-                }
-                const float sc = blob[o[YK_F_SCALE_OFF] + k], bs = blob[o[YK_F_BIAS_OFF] + k];
-                par[(size_t)9 * cp + k] = sc;
-                par[(size_t)10 * cp + k] = bs;
-                gain = std::max(gain, fabsf(sc) * sw);
-                off = std::max(off, fabsf(bs));
-            }
-            void *dp;
-            if ((rc = x_upload(p, &dp, par.data(), par.size() * sizeof(float)))) return fail(rc);
+            float gain, off;
+            if ((rc = pack_dw(o, c, cp, &d.par, &gain, &off))) return fail(rc);
             d.in = view_of(xid);
             d.Ho = Y.h; d.Wo = Y.w;
             d.stride = o[YK_F_STRIDE]; d.pad_t = o[YK_F_PAD_T]; d.pad_l = o[YK_F_PAD_L];
-            d.par = (const float *)dp;
             yk_act_params(o[YK_F_ACT], alpha, &d.slope, &d.cap);
-            d.gain = gain * 1.0001f;
-            d.off = off * 1.0001f;
+            d.gain = gain;
+            d.off = off;
             d.out = Y.d;
             d.eexp_out = eexp_of(yid);
             d.amax_out = amax_of(yid);
-            d.fd_g = yk_make_fastdiv((uint32_t)(cp >> 3));
-            d.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
-            l.lds = (unsigned)((size_t)11 * cp * 4);
-            snprintf(nm, sizeof nm, "x:dw3x3s%d_%d", d.stride, c);
+            xdw_geometry(d, max_batch);
+            l.lds = (unsigned)((size_t)d.n16p * 32);
+            snprintf(nm, sizeof nm, "x:dw3x3s%d_%d[%dx%dx%d]", d.stride, c, d.TH, d.TW, d.GS * 8);
             l.flops = 2.0 * Y.h * Y.w * 9 * c;
             l.bytes = ((double)X.h * X.w * c + (double)Y.h * Y.w * c) * 4;
         } else if (ty == YK_OP_MAXPOOL) {
@@ -1307,14 +1579,22 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             xg_args g = l.c;
             g.B = batch;
             g.M = batch * l.Ho * l.Wo;
+            if (const char *e = yk_dev_env("YK_X_DBG")) g.dbg = atoi(e);
             int rc = x_launch_conv(l.cfg, l.ns, g, st);
+            if (rc) return rc;
+        } break;
+        case XK_BLOCK: {
+            xb_args g = l.b;
+            g.B = batch;
+            if (const char *e = yk_dev_env("YK_XB_DBG")) g.dbg = atoi(e);
+            int rc = x_launch_block(l.tm, l.tn, g, batch, l.lds, st);
             if (rc) return rc;
         } break;
         case XK_DW: {
             xdw_args d = l.d;
             d.B = batch;
-            const unsigned per_image = (unsigned)d.Ho * d.Wo * d.in.G;
-            hipLaunchKernelGGL(xdw_kernel, dim3((per_image + 255) / 256, batch), dim3(256), l.lds, st, d);
+            if (const char *e = yk_dev_env("YK_X_DWDBG")) d.dbg = atoi(e);
+            hipLaunchKernelGGL(xdw_kernel, dim3((unsigned)(batch * d.tiles_x * d.tiles_y * d.gsl)), dim3((unsigned)((d.NT + 63) & ~63)), l.lds, st, d);
         } break;
         case XK_POOL: {
             xpool_args q = l.p;

@@ -1,0 +1,308 @@
+// yk_xblock.h — f16x2 mode: DepthwiseConv2D 3x3 + BN + act -> Conv2D 1x1 + BN + act (+ residual Add) in ONE launch (included by
+// yk_exact.hip).  MobileNet block: keras_mobilenet.py:359-436, keras_mobilenet_v2.py:452-481.
+//
+// A workgroup (4 waves) owns a TH x TW patch of output pixels of ONE image (BM = 16*TM >= TH*TW GEMM rows) and BN = 64*TN output
+// channels (wave w: channels [w*16*TN, (w+1)*16*TN) of all BM pixels).  The channel axis is walked in steps of 32 (four groups of 8):
+//
+//   DMA(k)    one burst of `buffer_load ... lds` into stage k % 2: the input patch of the step's four channel groups
+//             ((TH-1)s+3 x (TW-1)s+3 positions x 4 groups, hi and lo halves in separate regions; pixels outside the image and groups
+//             past the tensor's last one get an out-of-range offset and arrive as zeros), the step's slice of the depthwise
+//             parameter table (nine taps, scale, bias x 32 channels fp32) and the pointwise weight tile [BN][32] (hi | lo, host order)
+//   dw(k)     one thread = one (pixel, channel group): nine taps from LDS, fp32 FMA chain, BN + activation, scaled by the MIDDLE
+//             exponent and split into (hi, lo) straight into the MFMA A tile - the depthwise tensor never exists in HBM
+//   mma(k)    A x B on v_mfma_f32_16x16x32_f16, three products per tile
+//
+// Single-buffered and phase-shifted (two s_barriers per step): the patch of step k+1 is requested when dw(k) is over and lands under
+// mma(k); the weight tile of step k is requested when mma(k-1) is over and lands under dw(k).  One stage of everything keeps the
+// workgroup at ~70 KB for 384 output channels, so two workgroups share a CU and each one's depthwise (VALU) phase runs under the
+// other's MFMA phase.  The output tile leaves through LDS in passes of IPP row blocks (a whole 64 x 384 tile would need 99 KB).  The depthwise tensor's maximum is never measured, so
+// its exponent comes from its bound (gain_dw * amax(in) + off_dw) and the pointwise bound is built on that bound; the two levels of
+// over-estimate (2^3 x 2^7 in these networks) stay far inside fp16's exponent range (see the header of yk_exact.hip).
+#pragma once
+
+struct xb_args {
+    xview in, res;                     // res.p null without a residual
+    int B, Ho, Wo, N;
+    int stride, pad_t, pad_l;
+    const float *par;                  // [11][Cp] fp32: nine depthwise taps, scale, bias
+    int nk;                            // k-steps = ceil(G / 4)
+    float dw_slope, dw_cap, dw_gain, dw_off;
+    const uint8_t *w;                  // pointwise weights [nk][nslab][2][16][32] halfs
+    uint32_t w_bytes;
+    int nslab;
+    const float *scale, *bias;         // pointwise BN (scale carries 2^-s of the weight split)
+    float slope, cap, gain, off;       // |pointwise output| <= gain * bound(dw) + off
+    uint8_t *out;
+    int outG;
+    int *eexp_out;
+    uint32_t *amax_out;
+    // geometry, fixed at plan creation
+    int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
+    yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw;
+    int dbg;
+};
+
+template <int TM, int TN>
+struct xb_cfg {
+    static constexpr int BM = 16 * TM, BN = 64 * TN;
+    static constexpr int PARB = 2048;                             // 11 x 32 floats = 88 DMA slots of 16 B, deposited by two whole waves (128 slots)
+    static constexpr int CPITCH = BN * 4 + 16;
+    static constexpr int IPP = (TN >= 3 && TM >= 2) ? (TM + 1) / 2 : TM;   // row blocks per output pass
+    static constexpr int ring(int n16p) { return n16p * 32 + PARB + BN * 128 + BM * 128; }
+    static constexpr int lds(int n16p) {
+        const int r = ring(n16p), ct = IPP * 16 * CPITCH;
+        return (r > ct ? r : ct) + 64;
+    }
+};
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb_args a) {   // 2 (3) workgroups per CU: <= 256 (168) registers
+    typedef xb_cfg<TM, TN> C;
+    constexpr int BM = C::BM, BN = C::BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = a.in.G, s = a.stride;
+    unsigned char *HI = xsm, *LO = xsm + a.n16p * 16, *PARb = xsm + a.n16p * 32, *Bs = PARb + C::PARB, *A = Bs + BN * 128;
+    const float *PAR = reinterpret_cast<const float *>(PARb);
+    float *sf = reinterpret_cast<float *>(xsm + C::lds(a.n16p) - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
+    uint32_t *smax = reinterpret_cast<uint32_t *>(sf + 8);
+    // block -> (image, tile); blockIdx.y = N slice
+    const int bid = x_xcd_tile(blockIdx.x, gridDim.x);
+    const uint32_t b = x_div((uint32_t)bid, a.fd_tpi), tl = bid - b * (a.tiles_x * a.tiles_y);
+    const uint32_t ty = x_div(tl, a.fd_tx), tx = tl - ty * a.tiles_x;
+    const int oy0 = (int)ty * a.TH, ox0 = (int)tx * a.TW;
+    const int iy0 = oy0 * s - a.pad_t, ix0 = ox0 * s - a.pad_l;
+    const int n0 = blockIdx.y * BN;
+    const int fr = lane & 15, fq = lane >> 4, nl4 = fq * 4;
+    // BatchNorm scale / bias of this lane's output channels: requested first, used last (narrow tiles only: 12 float4 pairs of a
+    // 384-wide tile would cost the second workgroup per CU its registers)
+    constexpr bool EARLY_SB = TN <= 2;
+    float4 sc[TN], bs[TN];
+    if constexpr (EARLY_SB) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wid * TN + j) * 16 + nl4;
+            sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
+            bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+        }
+    }
+    const uint32_t img = (uint32_t)a.in.H * a.in.W * G * 32u;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in.p + (size_t)b * img), 0, img, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void *)a.par, 0, (uint32_t)(11 * G * 32), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    // this lane's patch positions are the same for every step: precompute the source offsets of its (up to PQ) DMA slots
+    constexpr int PQ = 6;                                         // patch slots per lane: n16p <= PQ * 256
+    uint32_t poff[PQ];
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) {
+        const uint32_t q = (uint32_t)(i * 256 + tid);
+        const uint32_t pos = q >> 2, g4 = q & 3;
+        const uint32_t r = x_div(pos, a.fd_pw), c = pos - r * a.PW;
+        const int iy = iy0 + (int)r, ix = ix0 + (int)c;
+        const bool ok = (int)q < a.n16 && (unsigned)iy < (unsigned)a.in.H && (unsigned)ix < (unsigned)a.in.W;
+        poff[i] = ok ? (uint32_t)(((iy * a.in.W + ix) * G + (int)g4) * 32) : X_OOB;
+    }
+    const int g4l = tid & 3;
+    const uint32_t wbase = (uint32_t)(n0 >> 4) * 2048u + lane * 16u, wstep = (uint32_t)a.nslab * 2048u;
+    auto dma_patch = [&](int ks) {                                // patch + depthwise parameters of step ks
+        const bool gok = (ks * 4 + g4l) < G;
+        const uint32_t koff = gok ? (uint32_t)ks * 128u : X_OOB;
+#pragma unroll
+        for (int i = 0; i < PQ; ++i)
+            if (i * 256 + wid * 64 < a.n16p) {                    // wave-uniform: n16p is a multiple of 64, a wave deposits 64 slots
+                const uint32_t oh = poff[i] + koff, ol = oh + 16u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(HI + (i * 256 + wid * 64) * 16), 16, oh, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(LO + (i * 256 + wid * 64) * 16), 16, ol, 0, 0, 0);
+            }
+        if (wid < 2) {                                            // 11 rows x 8 pieces of 16 B = 88 slots
+            const int idx = wid * 64 + lane, t = idx >> 3, pc = idx & 7;
+            const int ch = ks * 32 + pc * 4;
+            const uint32_t op = (idx < 88 && ch < G * 8) ? (uint32_t)((t * G * 8 + ch) * 4) : X_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr_t)(PARb + wid * 1024), 16, op, 0, 0, 0);
+        }
+    };
+    auto dma_b = [&](int ks) {                                    // pointwise weight tile of step ks
+        const uint32_t ws = wbase + (uint32_t)ks * wstep;
+#pragma unroll
+        for (int it = 0; it < (BN / 16 * 2 + 3) / 4; ++it) {
+            const int pc = it * 4 + wid;
+            if (pc < BN / 16 * 2) {
+                const uint32_t ob = ws + (uint32_t)pc * 1024u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Bs + pc * 1024), 16, ob, 0, 0, 0);
+            }
+        }
+    };
+    if (!(a.dbg & 1)) dma_patch(0);
+    // per-image factors (one image per workgroup)
+    if (wid == 0) {
+        const float amax_in = x_amax_wave(a.in.amax, (int)b);
+        const float bmid = fminf(a.dw_cap, a.dw_gain * amax_in + a.dw_off);
+        float bout = fminf(a.cap, a.gain * bmid + a.off);
+        float rup = 0.f;
+        if (a.res.p) {
+            bout += x_amax_wave(a.res.amax, (int)b);
+            rup = x_pow2(a.res.eexp[b]);
+        }
+        const int em = x_exp_of(__float_as_uint(bmid)), eo = x_exp_of(__float_as_uint(bout));
+        if (lane == 0) {
+            sf[0] = x_pow2(a.in.eexp[b]);
+            sf[1] = x_pow2(-em);
+            sf[2] = x_pow2(em);
+            sf[3] = x_pow2(-eo);
+            sf[4] = rup;
+            smax[0] = 0u;
+            a.eexp_out[b] = eo;
+        }
+    }
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) * 16);
+    const int nk = (a.dbg & 1) ? 0 : a.nk;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of patch(ks) have landed
+        __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
+        asm volatile("" ::: "memory");
+        dma_b(ks);
+        const float up = sf[0], dmid = sf[1];
+        // ---- depthwise: item = (pixel p, group q of this step)
+        if (!(a.dbg & 2))
+            for (int it = tid; it < BM * 4; it += 256) {
+                const int p = it >> 2, q = it & 3;
+                const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
+                const bool live = py < a.TH && oy0 + py < a.Ho && ox0 + px < a.Wo;
+                half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+                if (live) {
+                    const int base = ((py * s) * a.PW + px * s) * 4 + q;
+                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int at = (base + ((t / 3) * a.PW + (t % 3)) * 4) * 16;
+                        const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
+                        const float4 w0 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8), w1 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8 + 4);
+                        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {                 // x = hi + lo: two mixed-precision FMAs, no conversions
+                            x_fma_mix_lo(d[2 * j], h[j], w[2 * j]);
+                            x_fma_mix_lo(d[2 * j], l[j], w[2 * j]);
+                            x_fma_mix_hi(d[2 * j + 1], h[j], w[2 * j + 1]);
+                            x_fma_mix_hi(d[2 * j + 1], l[j], w[2 * j + 1]);
+                        }
+                    }
+                    const float *scd = PAR + 9 * 32 + q * 8, *bsd = PAR + 10 * 32 + q * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = x_actf(d[j] * up * scd[j] + bsd[j], a.dw_slope, a.dw_cap);
+                        yk_half h, l;
+                        x_split(v * dmid, h, l);
+                        hi[j] = h;
+                        lo[j] = l;
+                    }
+                }
+                const int r = p & 15;
+                unsigned char *dst = A + (p >> 4) * 2048 + r * 64 + ((q ^ ((r >> 1) & 3)) * 16);
+                *reinterpret_cast<half8 *>(dst) = hi;
+                *reinterpret_cast<half8 *>(dst + 1024) = lo;
+            }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // the A tile is complete, the weight tile has landed, the patch is free
+        asm volatile("" ::: "memory");
+        if (ks + 1 < nk) dma_patch(ks + 1);
+        // ---- pointwise: three products per tile
+        if (!(a.dbg & 16)) {
+            half8 xh[TM], xl[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                xh[i] = *reinterpret_cast<const half8 *>(A + i * 2048 + foff);
+                xl[i] = *reinterpret_cast<const half8 *>(A + i * 2048 + 1024 + foff);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wh[j] = *reinterpret_cast<const half8 *>(Bs + ((wid * TN + j) * 2) * 1024 + foff);
+                wl[j] = *reinterpret_cast<const half8 *>(Bs + ((wid * TN + j) * 2 + 1) * 1024 + foff);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // LDS becomes the output tile
+    asm volatile("" ::: "memory");
+    if (a.dbg & 4) return;
+    // ---- epilogue: lane holds channels n..n+3 of pixel i*16 + fr; the tile leaves through LDS in passes of IPP row blocks
+    unsigned char *Cs = xsm;
+    const float umid = sf[2], dout = sf[3], rup = sf[4];
+    float rmax = 0.f;
+    constexpr int VPR = BN / 4, IPP = C::IPP;
+    if constexpr (!EARLY_SB) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wid * TN + j) * 16 + nl4;
+            sc[j] = *reinterpret_cast<const float4 *>(a.scale + n);
+            bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
+        }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += IPP) {
+        if (i0 > 0) __syncthreads();                                  // the previous pass has been copied out
+#pragma unroll
+        for (int i = i0; i < i0 + IPP && i < TM; ++i) {
+            const int p = i * 16 + fr;
+            const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            const bool mok = py < a.TH && oy < a.Ho && ox < a.Wo;
+            const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wid * TN + j) * 16 + nl4, n = n0 + nl;
+                float v[4];
+                v[0] = x_actf(acc[i][j][0] * umid * sc[j].x + bs[j].x, a.slope, a.cap);
+                v[1] = x_actf(acc[i][j][1] * umid * sc[j].y + bs[j].y, a.slope, a.cap);
+                v[2] = x_actf(acc[i][j][2] * umid * sc[j].z + bs[j].z, a.slope, a.cap);
+                v[3] = x_actf(acc[i][j][3] * umid * sc[j].w + bs[j].w, a.slope, a.cap);
+                if (a.res.p && mok && (n >> 3) < a.res.G) {
+                    const uint8_t *q = a.res.p + (m * a.res.G + (n >> 3)) * 32 + (n & 7) * 2;
+                    const half4 rh = *reinterpret_cast<const half4 *>(q), rl = *reinterpret_cast<const half4 *>(q + 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * rup;
+                }
+                half4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (mok) rmax = fmaxf(rmax, fabsf(v[k]));
+                    yk_half h, l;
+                    x_split(v[k] * dout, h, l);
+                    hi[k] = h;
+                    lo[k] = l;
+                }
+                unsigned char *d = Cs + (p - i0 * 16) * C::CPITCH + (nl >> 3) * 32 + (nl & 7) * 2;
+                *reinterpret_cast<half4 *>(d) = hi;
+                *reinterpret_cast<half4 *>(d + 16) = lo;
+            }
+        }
+        __syncthreads();
+        const int rows = (TM - i0 < IPP ? TM - i0 : IPP) * 16;
+        for (int v = tid; v < rows * VPR; v += 256) {
+            const int pr = v / VPR, cv = v - pr * VPR, p = i0 * 16 + pr;
+            const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
+            const int oy = oy0 + py, ox = ox0 + px, g = (n0 >> 3) + (cv >> 1);
+            if (py < a.TH && oy < a.Ho && ox < a.Wo && g < a.outG)
+                *reinterpret_cast<u32x4 *>(a.out + ((((size_t)b * a.Ho + oy) * a.Wo + ox) * a.outG + g) * 32 + (cv & 1) * 16) =
+                    *reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16);
+        }
+    }
+    x_amax_lds(smax, 0, rmax);
+    __syncthreads();
+    if (tid == 0 && smax[0]) x_amax_global(a.amax_out + (size_t)b * XS, smax[0]);
+}

@@ -10,6 +10,8 @@ import torch
 import oracle
 from k210_yolo_framework_amd import engine, netspec as ns
 
+ALL = '--all' in sys.argv
+sys.argv = [v for v in sys.argv if v != '--all']
 name = sys.argv[1] if len(sys.argv) > 1 else 'yolo_mobilev1'
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 96
@@ -45,7 +47,12 @@ for op in spec.ops:
     worst = max(worst, rel)
     flag = '' if rel < 1e-4 else '   <<<<<<'
     print(f'tensor {t:3d} type {op["type"]} {op.get("layer", ""):24s} shape {tuple(ref.shape)} max|ref| {scale:10.4g} err {err:10.3g} rel {rel:9.2g} finite {bool(np.isfinite(got).all())}{flag}')
-    if rel > 1e-2 and '--all' not in sys.argv:
+    if rel > 1e-5 and '--detail' in os.environ.get('XL', ''):
+        e = np.abs(got - ref)
+        print('   per-channel max err (first 48):', np.array2string(e.reshape(-1, e.shape[-1]).max(0)[:48], precision=1, max_line_width=400))
+        pe = e.max(-1)[0]
+        print('   per-pixel max err image 0, rows 0-3:', np.array2string(pe[:4, :24], precision=1, max_line_width=400))
+    if not (rel <= 1e-2) and not ALL:
         bad = np.argwhere(np.abs(got - ref) > 1e-3 * scale)
         print('   first bad indices', bad[:8].tolist(), ' count', len(bad), 'of', got.size)
         print('   got', got[tuple(bad[0])], 'ref', ref[tuple(bad[0])])
