@@ -728,7 +728,11 @@ extern "C" int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_d
 // dev instrumentation: arm phase timestamps for launch `li`, run once (u8 path), copy out [n_wg][8] ticks (100 MHz)
 extern "C" int yk_debug_phase_stamps(yk_plan_t *p, int li, const uint8_t *d_frames, int batch, void *stream,
                                      long long *h_out, int max_wg) {
-    if (!p || p->x || li < 0 || li >= (int)p->L.size()) return YK_ERR_ARG;
+    if (p && p->x) {       // f16x2 plan: [n_wg][16] stamps of a fused block launch
+        YK_HIP(hipSetDevice(p->device));
+        return yk_xplan_phase_stamps(p->x, li, d_frames, batch, (hipStream_t)stream, h_out, max_wg);
+    }
+    if (!p || li < 0 || li >= (int)p->L.size()) return YK_ERR_ARG;
     YK_HIP(hipSetDevice(p->device));
     if (!p->d_dbg) {
         int rc = dev_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 8 * 65536, true);

@@ -1054,6 +1054,8 @@ struct yk_xplan {
     unsigned *d_imgmax = nullptr;
     uint32_t *d_amax = nullptr;        // [n_tensors][max_batch][XS]
     int *d_eexp = nullptr;             // [n_tensors][max_batch]
+    long long *d_dbg = nullptr;        // developer instrumentation (yk_xplan_phase_stamps)
+    int dbg_launch = -1;
 };
 
 static int x_alloc(yk_xplan *p, void **ptr, size_t bytes) {
@@ -1162,6 +1164,11 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             f.g.N = q[YK_F_COUT];
             f.g.stride = o[YK_F_STRIDE];
             f.g.nk = ((p->T[y].cp >> 3) + 3) / 4;
+            // measured (K2, B=32): one launch wins or ties down to 14x20 pixels per image; at 7x10 (2240 GEMM rows) the two-launch form
+            // is faster (28 vs 39 us, 34 vs 60 us): too few workgroups to hide the fused pipeline's per-step DMA round trips
+            // (the rule looks at the image only, not at max_batch: whether a block is fused changes its rounding, and an image's
+            // results must not depend on how many images the plan was built for)
+            if (f.g.Ho * f.g.Wo < 128 && !yk_dev_env("YK_XB_ALWAYS")) continue;
             if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch)) continue;
             dw_of[i + 1] = i;
             skip[i] = 1;
@@ -1587,6 +1594,7 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             xb_args g = l.b;
             g.B = batch;
             if (const char *e = yk_dev_env("YK_XB_DBG")) g.dbg = atoi(e);
+            g.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
             int rc = x_launch_block(l.tm, l.tn, g, batch, l.lds, st);
             if (rc) return rc;
         } break;
@@ -1651,6 +1659,24 @@ int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t d
             for (int c = 0; c < t.c; ++c)
                 dst[c] = ldexpf(x_h2f(src[(c >> 3) * 16 + (c & 7)]) + x_h2f(src[(c >> 3) * 16 + 8 + (c & 7)]), ee[b]);
         }
+    return YK_OK;
+}
+
+// dev instrumentation: arm phase timestamps for launch `li` (a fused block), run once, copy out [n_wg][16] ticks (100 MHz)
+int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipStream_t st, long long *h_out, int max_wg) {
+    if (li < 0 || li >= (int)p->L.size() || p->L[li].kind != XK_BLOCK) return YK_ERR_ARG;
+    const size_t cap = 65536;
+    if (!p->d_dbg) {
+        int rc = x_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 16 * cap);
+        if (rc) return rc;
+    }
+    YK_HIP(hipMemset(p->d_dbg, 0, sizeof(long long) * 16 * cap));
+    p->dbg_launch = li;
+    int rc = yk_xplan_run(p, d_in, 0, batch, st, nullptr);
+    p->dbg_launch = -1;
+    if (rc) return rc;
+    YK_HIP(hipStreamSynchronize(st));
+    YK_HIP(hipMemcpy(h_out, p->d_dbg, sizeof(long long) * 16 * std::min<size_t>(cap, (size_t)max_wg), hipMemcpyDeviceToHost));
     return YK_OK;
 }
 

@@ -40,6 +40,7 @@ struct xb_args {
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw;
     int dbg;
+    long long *stamps;                 // developer builds: per-workgroup phase timestamps [wg][16] (wall_clock64), or null
 };
 
 template <int TM, int TN>
@@ -61,6 +62,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     constexpr int BM = C::BM, BN = C::BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = a.in.G, s = a.stride;
+#define XB_STAMP(k) \
+    if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)wall_clock64();
+    XB_STAMP(0)
     unsigned char *HI = xsm, *LO = xsm + a.n16p * 16, *PARb = xsm + a.n16p * 32, *Bs = PARb + C::PARB, *A = Bs + BN * 128;
     const float *PAR = reinterpret_cast<const float *>(PARb);
     float *sf = reinterpret_cast<float *>(xsm + C::lds(a.n16p) - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
@@ -132,6 +136,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         }
     };
     if (!(a.dbg & 1)) dma_patch(0);
+    XB_STAMP(1)
     // per-image factors (one image per workgroup)
     if (wid == 0) {
         const float amax_in = x_amax_wave(a.in.amax, (int)b);
@@ -153,6 +158,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             a.eexp_out[b] = eo;
         }
     }
+    XB_STAMP(2)
     floatx4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -164,6 +170,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of patch(ks) have landed
         __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
         asm volatile("" ::: "memory");
+        if (ks == 0) { XB_STAMP(3) }
         dma_b(ks);
         const float up = sf[0], dmid = sf[1];
         // ---- depthwise: item = (pixel p, group q of this step)
@@ -205,9 +212,11 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                 *reinterpret_cast<half8 *>(dst) = hi;
                 *reinterpret_cast<half8 *>(dst + 1024) = lo;
             }
+        if (ks == 0) { XB_STAMP(4) }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // the A tile is complete, the weight tile has landed, the patch is free
         asm volatile("" ::: "memory");
+        if (ks == 0) { XB_STAMP(5) }
         if (ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile
         if (!(a.dbg & 16)) {
@@ -236,9 +245,11 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
         }
     }
+    XB_STAMP(6)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                     // LDS becomes the output tile
     asm volatile("" ::: "memory");
+    XB_STAMP(7)
     if (a.dbg & 4) return;
     // ---- epilogue: lane holds channels n..n+3 of pixel i*16 + fr; the tile leaves through LDS in passes of IPP row blocks
     unsigned char *Cs = xsm;
@@ -291,6 +302,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                 *reinterpret_cast<half4 *>(d + 16) = lo;
             }
         }
+        if (i0 == 0) { XB_STAMP(8) }
         __syncthreads();
         const int rows = (TM - i0 < IPP ? TM - i0 : IPP) * 16;
         for (int v = tid; v < rows * VPR; v += 256) {
@@ -302,7 +314,10 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                     *reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16);
         }
     }
+    XB_STAMP(9)
     x_amax_lds(smax, 0, rmax);
     __syncthreads();
     if (tid == 0 && smax[0]) x_amax_global(a.amax_out + (size_t)b * XS, smax[0]);
+    XB_STAMP(10)
+#undef XB_STAMP
 }
