@@ -70,12 +70,20 @@ class YoloModel:
         self._drop_plan()
 
     def load_weights(self, path: str, by_name: bool = False) -> None:
-        """keras_inference.py:80 / keras_train.py:52-57.  `.h5`/`.hdf5`: a Keras weight or full-model file; otherwise `.npz`.
+        """keras_inference.py:80 / keras_train.py:52-57.  `.h5`/`.hdf5`: a Keras weight or full-model file; `.kmodel`/`.kfpkg`: the
+        K210 demo's quantised yolo_mobilev1-0.75 (kmodel.py); otherwise `.npz`.
         by_name=True accepts a file that covers only part of the network (backbone pre-train files, yolonet.py:16-21)."""
         path = str(path)
         if path.endswith(('.h5', '.hdf5', '.keras')):
             from . import keras_io
             w, self.last_load_report = keras_io.load_keras_weights(self.spec, path, base=self._s['weights'], strict=not by_name)
+            self.set_weights(w)
+            return
+        if path.endswith(('.kmodel', '.kfpkg')):
+            # the K210 demo's 8-bit model (yolo3_frame_test_public/kfpkg/kpu_yolov3.kfpkg -> yolo.kmodel, main.c:57,213,274), dequantised
+            from . import kmodel
+            data = kmodel.read_kfpkg(path) if path.endswith('.kfpkg') else open(path, 'rb').read()
+            w, self.last_load_report = kmodel.to_float_weights(kmodel.parse(data))
             self.set_weights(w)
             return
         with np.load(path) as z:
