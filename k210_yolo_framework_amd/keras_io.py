@@ -179,8 +179,12 @@ def load_keras_weights(spec: ns.NetSpec, path, base: Optional[Dict[str, np.ndarr
 
 
 def save_keras_weights(spec: ns.NetSpec, weights: Dict[str, np.ndarray], path, tf_keras_names: bool = True) -> None:
-    """Write `weights` in the Keras layout above (what keras_train.py:105-109 leaves in log/<time>/yolo_model.h5).  Layers are
-    written in creation order; auto-named layers get tf.keras 1.14 names ('conv2d', 'conv2d_1', ...; 'batch_normalization', ...)."""
+    """Write `weights` in Keras' `save_weights` HDF5 layout (root attribute `layer_names`, one group per layer with `weight_names`).
+    NOTE the format: the reference's keras_train.py:105-109 calls `keras.models.save_model`, whose file additionally carries the
+    architecture (`model_config`) and nests the same tree under `/model_weights`; this writer produces the WEIGHTS-ONLY file - what
+    `model.load_weights(path)` reads on the reference side (keras_inference.py:80 does exactly that), not what `load_model` /
+    `TFLiteConverter.from_keras_model_file` (keras_freeze.py:15-23) need.  The reader (`read_keras_h5`) accepts both layouts.
+    Layers are written in creation order; auto-named layers get tf.keras 1.14 names ('conv2d', 'conv2d_1', ...)."""
     tree, order = {}, []
     n_conv = n_bn = 0
 

@@ -83,6 +83,7 @@ class Trainer:
         self._graph = None
         self._gx = self._gy = self._gres = self._side = None
         self._eager_steps = 0
+        self._captured_key = None
 
     # ------------------------------------------------------------------ parameters
     def view(self, buf, name):
@@ -104,7 +105,15 @@ class Trainer:
                 for s in ('/gamma', '/beta'):
                     self.view(self.P, l.bn_name + s).copy_(torch.from_numpy(np.asarray(weights[l.bn_name + s], np.float32)))
                 for s in ('/moving_mean', '/moving_variance'):
-                    self.moving[l.bn_name + s] = torch.from_numpy(np.asarray(weights[l.bn_name + s], np.float32).copy()).to(self.dev)
+                    src = torch.from_numpy(np.asarray(weights[l.bn_name + s], np.float32).copy())
+                    cur = self.moving.get(l.bn_name + s)
+                    if cur is None:
+                        self.moving[l.bn_name + s] = src.to(self.dev)
+                    else:
+                        # IN PLACE: a captured step holds the raw pointer of this tensor (yk_bn_train_fwd updates the moving statistics
+                        # inside the replayed graph); rebinding the name would leave the graph writing a freed buffer while
+                        # export_weights / validate read a tensor nobody updates
+                        cur.copy_(src)
 
     def export_weights(self) -> Dict[str, np.ndarray]:
         """Keras-layout arrays again (what keras.models.save_model would hold, keras_train.py:107)."""
@@ -344,11 +353,26 @@ class Trainer:
         reg = self.regulariser(add_grad=self.world == 1)
         return dict(layers=parts, reg=reg)
 
+    def invalidate_graph(self) -> None:
+        """Forget the captured step (the next two steps run eagerly / re-capture).  Called automatically when something a capture
+        bakes in as a launch scalar or a shape changes: `tr.hyper[...]`, the batch shape.  Parameters, Adam state and BatchNorm moving
+        statistics live in buffers that are only ever written in place, so loading weights does not need it."""
+        self._graph = None
+        self._gres = self._gx = self._gy = None
+        self._eager_steps = 0
+
+    def _graph_key(self, x_nhwc, y_true):
+        return (tuple(sorted(self.hyper.items())), tuple(x_nhwc.shape), tuple(tuple(y.shape) for y in y_true), self.world)
+
     def _loss_and_grads_replayed(self, x_nhwc, y_true):
-        """loss_and_grads through a captured HIP graph (after one eager step that also warms allocator and scratch buffers)."""
+        """loss_and_grads through a captured HIP graph (after one eager step that also warms allocator and scratch buffers).
+        One Trainer per stream: the library's split-K workspace is keyed by the stream handle and is part of the capture."""
         torch = self.torch
         if not self.use_graph:
             return self.loss_and_grads(x_nhwc, y_true)
+        key = self._graph_key(x_nhwc, y_true)
+        if self._graph is not None and key != self._captured_key:
+            self.invalidate_graph()                                # loss weights / thresholds / shapes are launch arguments of the capture
         if self._graph is None:
             # both the eager first step and the capture run on one dedicated stream: the library's scratch buffers are keyed by
             # stream and must already have their final size when the capture starts (an allocation would invalidate it)
@@ -371,6 +395,7 @@ class Trainer:
                     self._gres = self.loss_and_grads(self._gx, self._gy)
             cur.wait_stream(side)
             self._graph = g
+            self._captured_key = key
             # the capture itself does not execute: fall through to a replay with the current batch
         self._gx.copy_(x_nhwc)
         for d, s_ in zip(self._gy, y_true):

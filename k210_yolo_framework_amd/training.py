@@ -5,8 +5,9 @@ is `train.Trainer.step` here; the tf.data pipeline (tools/utils.py:417-450 `_cre
 `box_to_label`, batch) is the plain-python `batches()` generator below (row N3).  Validation runs the fp16 inference
 engine on the exported weights (BatchNorm with moving statistics, like Keras' test phase).
 
-Checkpoints: `log/<time>/yolo_model.h5` in the Keras HDF5 layout (keras_io / h5lite, no h5py needed) plus the same arrays as
-`yolo_model.npz`; `--pre_ckpt` takes either.  Differences, reported at run time: imgaug augmentation and tfmot pruning are out of
+Checkpoints: `log/<time>/yolo_model.h5` in Keras' WEIGHTS-ONLY HDF5 layout (`model.save_weights` format: readable by the reference's
+`load_weights`, keras_inference.py:80; it is not a `save_model` file - no `model_config` - so `keras_freeze.py`'s `load_model` cannot
+open it; keras_io / h5lite, no h5py needed) plus the same arrays as `yolo_model.npz`; `--pre_ckpt` takes either.  Differences, reported at run time: imgaug augmentation and tfmot pruning are out of
 scope (SURVEY.md section 2 #6/#9) and raise instead of silently doing nothing."""
 from __future__ import annotations
 

@@ -93,7 +93,8 @@ class YoloModel:
         self.set_weights(have)
 
     def save_weights(self, path: str) -> None:
-        """keras_train.py:105-109 (`keras.models.save_model(yolo_model, ...)`): `.h5` -> Keras layout, else `.npz`."""
+        """The checkpoint of keras_train.py:105-109, weights only: `.h5` -> Keras `save_weights` layout (what the reference's
+        `load_weights` reads; not a `save_model` file with `model_config`), else `.npz`."""
         path = str(path)
         if path.endswith(('.h5', '.hdf5')):
             from . import keras_io

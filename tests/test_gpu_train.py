@@ -362,6 +362,35 @@ def test_graph_replayed_step_equals_the_eager_step_bitwise():
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
 
 
+def test_reloading_weights_and_changing_hyper_parameters_after_a_replayed_step():
+    """ADVICE (round 2): the captured graph bakes in raw pointers and launch scalars.  load_weights() must write the BatchNorm moving
+    statistics IN PLACE (the replayed kernels keep updating the buffers export_weights() reads), and a change of tr.hyper must drop
+    the capture.  Reference behaviour: keras load_weights / compile with new loss weights, then fit again (keras_train.py:52-98)."""
+    from k210_yolo_framework_amd.train import Trainer
+    spec, w, h, x, yt = _case('yolo_mobilev1', (64, 96), 4, 0.5, 23)
+    xs, ys = _cu(x), [_cu(y) for y in yt]
+
+    def run(graph, obj_weight_after):
+        tr = Trainer(spec, w, h.anchors, 4, use_graph=graph)
+        for _ in range(3):                                                    # eager, capture + replay, replay
+            tr.step(xs, ys)
+        tr.load_weights(w)                                                    # back to the start (parameters AND moving statistics)
+        tr.m.zero_(); tr.v.zero_(); tr.iterations = 0
+        if obj_weight_after is not None:
+            tr.hyper['obj_weight'] = obj_weight_after
+        out = [tr.step(xs, ys) for _ in range(2)]
+        return out, tr.export_weights(), tr.G.cpu().numpy().copy()
+    for ow in (None, 3.0):
+        (le, we, ge), (lg, wg, gg) = run(False, ow), run(True, ow)
+        assert [o['loss'] for o in le] == [o['loss'] for o in lg], ow
+        assert np.array_equal(ge, gg), ow
+        for k in we:
+            assert np.array_equal(we[k], wg[k]), (ow, k)                      # includes every moving_mean / moving_variance
+    # and the moving statistics did move after the reload (they are not the loaded values any more)
+    k = spec.layers[0].bn_name + '/moving_mean'
+    assert not np.array_equal(wg[k], np.asarray(w[k], np.float32))
+
+
 def test_full_size_config3_step_mobilev2_b16_loss_and_gradient_direction():
     """BASELINE configs[3] at full size (yolo_mobilev2 1.0, 224x320, 16 images).  With ~1e8 activations some gates always flip
     between fp32 and float64, so gradients are compared by direction and norm per tensor instead of element-wise."""
