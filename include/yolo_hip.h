@@ -212,6 +212,10 @@ int yk_region_batched(const yk_region_cfg_t *cfg, const float *d_input, int batc
  * (The `img / np.max(img)` that follows, utils.py:405, is fused into yk_run_u8.) */
 int yk_letterbox_u8(const uint8_t *d_src, int batch, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
                     void *stream);
+/* `img / np.max(img)` (tools/utils.py:405) for a batch of u8 frames of per_image bytes each -> fp32 (one correctly rounded quotient
+ * per element, numpy's float64 division then the pipeline's float32 cast).  Used by the training input pipeline (N3); the inference
+ * path fuses the normalisation into the stem conv (yk_run_u8). */
+int yk_normalise_u8(const uint8_t *d_frames, int batch, size_t per_image, float *d_out, void *stream);
 
 /* ---- training step, loss level (tools/utils.py:708-793 create_loss_fn, :662-705 calc_ignore_mask,
  *      tools/custom.py:13-75 Yolo_Precision/Yolo_Recall) for ONE output layer.

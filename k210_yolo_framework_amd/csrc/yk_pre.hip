@@ -58,3 +58,47 @@ extern "C" int yk_letterbox_u8(const uint8_t *d_src, int batch, int src_h, int s
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
+
+// ---- `img / np.max(img)` (tools/utils.py:405) for a batch of u8 frames -> fp32, for the TRAINING input pipeline (the inference
+// path fuses it into the stem conv).  numpy divides in float64 and the pipeline then casts to float32 (utils.py:436 py_function
+// output type): one correctly rounded quotient per element.
+__global__ void __launch_bounds__(1024) u8_image_max_kernel(const uint8_t *__restrict__ f, size_t per_image, unsigned *__restrict__ mx) {
+    __shared__ unsigned part[16];
+    const uint8_t *p = f + (size_t)blockIdx.x * per_image;
+    unsigned m = 0;
+    for (size_t i = threadIdx.x; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = max(m, part[i]);
+        mx[blockIdx.x] = m;
+    }
+}
+__global__ void __launch_bounds__(256) u8_normalise_kernel(const uint8_t *__restrict__ f, size_t per_image, const unsigned *__restrict__ mx,
+                                                           float *__restrict__ out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const unsigned m = mx[i / per_image];
+    out[i] = (float)((double)f[i] / (double)m);                   // max 0 -> nan/inf exactly like numpy's 0/0 (an all-black image)
+}
+extern "C" int yk_normalise_u8(const uint8_t *d_frames, int batch, size_t per_image, float *d_out, void *stream) {
+    if (!d_frames || !d_out || batch <= 0 || per_image == 0) {
+        yk_set_error("yk_normalise_u8: bad argument");
+        return YK_ERR_ARG;
+    }
+    const int dev = yk_current_device();
+    if (dev < 0) {
+        yk_set_error("yk_normalise_u8: no HIP device");
+        return YK_ERR_NO_DEVICE;
+    }
+    unsigned *mx = (unsigned *)yk_scratch(dev, stream, 16, sizeof(unsigned) * (size_t)batch);
+    if (!mx) return YK_ERR_NOMEM;
+    hipLaunchKernelGGL(u8_image_max_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, d_frames, per_image, mx);
+    const size_t total = (size_t)batch * per_image;
+    hipLaunchKernelGGL(u8_normalise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_frames, per_image, mx,
+                       d_out, total);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}

@@ -2,7 +2,8 @@
 
 Same CLI and the same `main(...)` parameter list as the reference script.  What `train_model.fit` did inside TensorFlow
 is `train.Trainer.step` here; the tf.data pipeline (tools/utils.py:417-450 `_create_dataset`: shuffle, read, letterbox,
-`box_to_label`, batch) is the plain-python `batches()` generator below (row N3).  Validation runs the fp16 inference
+`box_to_label`, batch) is `pipeline.InputPipeline` (row N3: per-rank shards, thread-pool decode, GPU letterbox / normalise, two batches of prefetch); the
+plain-python `batches()` generator below is its host-only twin (tests compare the two bit for bit).  Validation runs the fp16 inference
 engine on the exported weights (BatchNorm with moving statistics, like Keras' test phase).
 
 Checkpoints: `log/<time>/yolo_model.h5` in Keras' WEIGHTS-ONLY HDF5 layout (`model.save_weights` format: readable by the reference's
@@ -120,13 +121,15 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
     tr = Trainer(spec, weights, h.anchors, per_rank, obj_thresh=obj_thresh, iou_thresh=iou_thresh, obj_weight=obj_weight,
                  noobj_weight=noobj_weight, wh_weight=wh_weight, lr=init_learning_rate, decay=learning_rate_decay_factor, device=local,
                  world_size=world)
-    rng = np.random.default_rng(rand_seed)
+    from .pipeline import InputPipeline
     steps = 0
     for epoch in range(max_nrof_epochs):
         t0, seen, run = time.time(), 0, 0.0
-        for x, ys in batches(h, h.train_list, batch_size, rng, shuffle=True):
-            sl = slice(rank * per_rank, (rank + 1) * per_rank)                   # every rank builds the same batch, keeps its slice
-            out = tr.step(torch.from_numpy(x[sl]).cuda(), [torch.from_numpy(y[sl]).cuda() for y in ys])
+        # tools/utils.py:417-450: each rank decodes only its rows of the global batch, on a thread pool, two batches ahead;
+        # letterbox + normalise on the GPU (pipeline.py)
+        pipe = InputPipeline(h, h.train_list, batch_size, rank, world, seed=rand_seed, epoch=epoch, shuffle=True, device=local)
+        for x, ys in pipe:
+            out = tr.step(x, ys)
             seen, run, steps = seen + 1, run + out['loss'], steps + 1
             if rank == 0 and (seen % 10 == 0 or seen == 1):
                 pr = tr.precision_recall()
@@ -134,10 +137,13 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
                       ' '.join(f'l{i + 1}_p {p:.3f} l{i + 1}_r {r:.3f}' for i, (p, r) in enumerate(pr)), flush=True)
             if max_steps and steps >= max_steps:
                 break
+        pipe_rate = pipe.producer_images_per_sec()
+        pipe.close()
         val = validate(tr, h, spec, per_rank, rank) if rank == 0 and len(h.test_list) >= per_rank else None
         if rank == 0:
             print(f'epoch {epoch + 1}: {seen} steps, mean loss {run / max(seen, 1):.4f}, ' +
-                  (f'val_loss {val:.4f}, ' if val is not None else '') + f'{time.time() - t0:.1f}s', flush=True)
+                  (f'val_loss {val:.4f}, ' if val is not None else '') + f'{time.time() - t0:.1f}s, input pipeline {pipe_rate:.0f} images/s/rank',
+                  flush=True)
         for c in tr.counts:
             c.zero_()                                                           # Keras resets metrics every epoch
         if max_steps and steps >= max_steps:
