@@ -190,6 +190,12 @@ typedef struct {
  * are ordered by ascending box index (TF leaves it unspecified). */
 int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
                  float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, void *stream);
+/* The same, also returning which box each row is: d_box_index [batch][C*max_out] int32 (may be NULL), the row's index into the
+ * reference's flattened (layer, h, w, anchor) box list (keras_inference.py:107-114: `tf.reshape(..., (-1, 4))` per layer, concatenated) -
+ * what `tf.boolean_mask` + `tf.image.non_max_suppression` + `tf.gather` select (:116-131). */
+int yk_decode_py_ex(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                    float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, int32_t *d_box_index,
+                    void *stream);
 
 /* C-mode (region_layer.c:121-283) for a batch of layer outputs without host round trips.
  * d_input element (b, anchor n, entry e, row y, col x) is at

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
 __global__ void __launch_bounds__(256) compact_py_kernel(int ntot, int C, int max_out, const float4 *__restrict__ boxes,
                                                          const int *__restrict__ sel_g, const float *__restrict__ sel_s,
                                                          const int *__restrict__ cnt, float *__restrict__ dets,
-                                                         int *__restrict__ counts) {
+                                                         int *__restrict__ counts, int *__restrict__ box_index) {
     extern __shared__ int base[];                   // [C + 1] exclusive prefix of the per-class counts
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(256) compact_py_kernel(int ntot, int C, int ma
             d[3] = bb.w;
             d[4] = sel_s[((size_t)b * C + c) * max_out + j];
             d[5] = (float)c;
+            if (box_index) box_index[(size_t)b * C * max_out + base[c] + j] = g;
         }
     }
 }
@@ -372,6 +373,12 @@ __global__ void __launch_bounds__(256) compact_py_kernel(int ntot, int C, int ma
 extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
                             float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts,
                             void *stream) {
+    return yk_decode_py_ex(cfg, d_pred, batch, d_image_hw, obj_thresh, iou_thresh, max_out, d_dets, d_counts, nullptr, stream);
+}
+
+extern "C" int yk_decode_py_ex(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                               float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts,
+                               int32_t *d_box_index, void *stream) {
     if (!cfg || !d_pred || !d_dets || !d_counts || batch <= 0 || max_out <= 0 || cfg->n_layers <= 0 ||
         cfg->n_layers > YK_MAX_LAYERS || cfg->anchor_num <= 0 || cfg->anchor_num > YK_MAX_ANCHORS ||
         cfg->class_num <= 0) {
@@ -432,7 +439,7 @@ extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pr
         hipLaunchKernelGGL(nms_py_kernel<2048>, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out, boxes, scores_t,
                            sel_g, sel_s, cnt);
     hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(256), (a.C + 1) * sizeof(int), st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
-                       d_dets, d_counts);
+                       d_dets, d_counts, d_box_index);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

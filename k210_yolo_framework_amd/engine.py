@@ -68,7 +68,7 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
                    'yk_bias_add_f32', 'yk_colsum_f32', 'yk_upsample2x_bwd_f32', 'yk_maxpool2_fwd_f32',
@@ -233,9 +233,10 @@ def make_decode_cfg(anchors: np.ndarray, class_num: int, in_hw, out_hw) -> Decod
 
 
 def decode_py(cfg: DecodeCfg, preds: Sequence, batch: int, image_hw=None, obj_thresh: float = 0.7,
-              iou_thresh: float = 0.5, max_out: int = 30, stream=None):
+              iou_thresh: float = 0.5, max_out: int = 30, stream=None, return_index: bool = False):
     """Batched keras_inference.py:94-135 on the GPU.  preds: cuda fp32 tensors [>=batch,h,w,A*(5+C)].
-    -> (dets [batch, C*max_out, 6] cuda fp32, counts [batch] cuda int32)."""
+    -> (dets [batch, C*max_out, 6] cuda fp32, counts [batch] cuda int32[, box_index [batch, C*max_out] cuda int32: each row's index
+    in the reference's flattened (layer, h, w, anchor) box list])."""
     import torch
     require_gpu()
     dev = preds[0].device
@@ -245,6 +246,12 @@ def decode_py(cfg: DecodeCfg, preds: Sequence, batch: int, image_hw=None, obj_th
     ihw = None
     if image_hw is not None:
         ihw = torch.as_tensor(np.broadcast_to(np.asarray(image_hw, np.float32), (batch, 2)).copy(), device=dev)
+    if return_index:
+        index = torch.full((batch, cfg.class_num * max_out), -1, dtype=torch.int32, device=dev)
+        _check(lib().yk_decode_py_ex(C.byref(cfg), arr, C.c_int(batch), _ptr(ihw) if ihw is not None else None,
+                                     C.c_float(obj_thresh), C.c_float(iou_thresh), C.c_int(max_out), _ptr(dets), _ptr(counts),
+                                     _ptr(index), _stream(stream)), 'yk_decode_py_ex')
+        return dets, counts, index
     _check(lib().yk_decode_py(C.byref(cfg), arr, C.c_int(batch), _ptr(ihw) if ihw is not None else None,
                               C.c_float(obj_thresh), C.c_float(iou_thresh), C.c_int(max_out), _ptr(dets), _ptr(counts),
                               _stream(stream)), 'yk_decode_py')

@@ -32,11 +32,12 @@ def _gpu(spec, w, frames, obj, iou, image_hw=None, precision='f16'):
     plan = engine.Plan(spec, w, max_batch=B, precision=precision)
     plan.run_u8(torch.from_numpy(frames).cuda())
     cfg = engine.make_decode_cfg(VOC_ANCHORS, spec.class_num, spec.in_hw, spec.out_hw())
-    dets, counts = engine.decode_py(cfg, plan.outputs(), B, image_hw, obj, iou)
+    dets, counts, index = engine.decode_py(cfg, plan.outputs(), B, image_hw, obj, iou, return_index=True)
     torch.cuda.synchronize()
     outs = [o[:B].cpu().numpy() for o in plan.outputs()]
-    d, c = dets.cpu().numpy(), counts.cpu().numpy()
+    d, c, ix = dets.cpu().numpy(), counts.cpu().numpy(), index.cpu().numpy()
     plan.close()
+    _gpu.last_index = [ix[b, :c[b]] for b in range(B)]
     return outs, [d[b, :c[b]] for b in range(B)]
 
 
@@ -62,6 +63,21 @@ def _match(got, ref_dets, ref_scores_all, obj, hw):
     if es_all:
         assert np.mean(es_all) <= 1e-3, np.mean(es_all)          # the north-star figure holds on average
     return paired, len(r), len(g)
+
+
+def _assert_exact_indices(index, ref, tag):
+    """BASELINE north_star "class/box indices bit-exact": per image the SET of (class, box index) pairs the GPU selected equals the
+    fp32 oracle's (keras_inference.py:116-131: boolean_mask + non_max_suppression + gather); inside a class the order is by score,
+    which is only defined up to the logit error, so the comparison is on sets, and additionally on sequences wherever the scores of
+    neighbouring detections differ by more than that error."""
+    n = 0
+    for b, (gi, (rd, ri)) in enumerate(zip(index, ref)):
+        assert len(gi) == len(ri), (tag, b, len(gi), len(ri))
+        got = sorted(zip(_gpu.last_dets_cls[b].tolist(), gi.tolist()))
+        want = sorted(zip(rd[:, 5].astype(int).tolist(), ri.tolist()))
+        assert got == want, (tag, b, [x for x in got if x not in want][:5], [x for x in want if x not in got][:5])
+        n += len(ri)
+    return n
 
 
 def _assert_north_star(dets, ref_dets, tag):
@@ -102,6 +118,8 @@ def test_north_star_tolerance_headline_config_all_32_images():
     rd = dr.decode_batch([r.reshape(32, r.shape[1], r.shape[2], 3, 25) for r in ref32], VOC_ANCHORS, (224, 320), (224, 320), 0.7, 0.5)
     n = _assert_north_star(dets, [x[0] for x in rd], 'K2 f16x2')
     assert n > 1000, n                                                          # ~350 detections per image on these weights
+    _gpu.last_dets_cls = [d[:, 5].astype(int) for d in dets]
+    assert _assert_exact_indices(_gpu.last_index, rd, 'K2 f16x2') == n          # the box INDEX of every detection, exact
 
 
 @pytest.mark.parametrize('name,shape,alpha,B', [('yolo_mobilev2', (224, 320, 3), 1.0, 4), ('tiny_yolo', (416, 416, 3), 1.0, 2)])
@@ -113,6 +131,8 @@ def test_north_star_tolerance_other_networks(name, shape, alpha, B):
     ref32 = oracle.net_forward(spec.compile_plan(w), oracle.normalise_u8(frames), emulate_f16=False, out_ids=spec.outputs)
     rd = dr.decode_batch([r.reshape(B, r.shape[1], r.shape[2], 3, 25) for r in ref32], VOC_ANCHORS, shape[:2], shape[:2], 0.7, 0.5)
     assert _assert_north_star(dets, [x[0] for x in rd], name) > 50
+    _gpu.last_dets_cls = [d[:, 5].astype(int) for d in dets]
+    assert _assert_exact_indices(_gpu.last_index, rd, name) > 50
 
 
 def test_make_inference_cli_prints_the_reference_table(tmp_path, capsys):
