@@ -984,28 +984,33 @@ int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hi
     yk_set_error("f16x2: no fused block kernel <%d,%d>", tm, tn);
     return YK_ERR_ARG;
 }
-unsigned xb_lds(int tm, int tn, int n16p) {
+unsigned xb_lds(int tm, int tn, int n16p, int db) {
     const int bm = 16 * tm, bn = 64 * tn;
     const int ipp = (tn >= 3 && tm >= 2) ? (tm + 1) / 2 : tm;
-    const int ring = n16p * 32 + 2048 + bn * 128 + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
+    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + bn * 128) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
     return (unsigned)(std::max(ring, ct) + 64);
 }
-// tile geometry of a fused block for max_batch images, by a small cost model (cycles).  Per step a workgroup spends a depthwise pass
-// of its 256 threads over BM*4 items (~700 cycles each round) and TM*TN*3 MFMAs per wave, plus the exposed part of the step's DMA; a
-// fixed prologue / epilogue; co-resident workgroups (LDS permitting) overlap each other's phases partly.  The whole N in one
-// workgroup is preferred (an N split repeats the depthwise work).  Returns false when nothing fits (the caller then keeps the
-// two-launch form).
-bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int max_batch) {
+// Tile geometry of a fused block.  Measured on K2 at B=32 (tools/xbsweep.py: every (TM, TN, tile width, stages) per block): the launch
+// time moves by only a few per cent across geometries, and what wins everywhere is THREE co-resident workgroups per CU (<= 53 KB of
+// LDS each; their DMA, depthwise and MFMA phases overlap) with the whole N (up to 192 channels) in one workgroup and one stage;
+// two stages never paid (they halve the co-residency).  So: N tile = min(192, N rounded up to 64); among the tiles that fit 53 KB the
+// one with the most pixels, then the least halo.  Returns false when nothing fits (the caller keeps the two-launch form).
+bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int max_batch, int ordinal) {
     const int s = g.stride;
     double best = -1.0;
-    const int force_tm = yk_dev_env("YK_XB_TM") ? atoi(yk_dev_env("YK_XB_TM")) : 0, force_tn = yk_dev_env("YK_XB_TN") ? atoi(yk_dev_env("YK_XB_TN")) : 0;
-    const int force_tw = yk_dev_env("YK_XB_TW") ? atoi(yk_dev_env("YK_XB_TW")) : 0;
+    const bool mine = !yk_dev_env("YK_XB_LAYER") || atoi(yk_dev_env("YK_XB_LAYER")) == ordinal;   // developer sweeps: force one block only
+    const int force_tm = mine && yk_dev_env("YK_XB_TM") ? atoi(yk_dev_env("YK_XB_TM")) : 0, force_tn = mine && yk_dev_env("YK_XB_TN") ? atoi(yk_dev_env("YK_XB_TN")) : 0;
+    const int force_tw = mine && yk_dev_env("YK_XB_TW") ? atoi(yk_dev_env("YK_XB_TW")) : 0;
+    const int force_db = mine && yk_dev_env("YK_XB_DB") ? atoi(yk_dev_env("YK_XB_DB")) : -1;
+    const bool forced = force_tm || force_tn || force_tw || force_db >= 0;
+    const int tn_want = std::min(3, (g.N + 63) / 64);
+    (void)max_batch;
     for (int tm : g_xb_tm)
         for (int tn : g_xb_tn) {
             if (!xb_has(tm, tn) || (force_tm && tm != force_tm) || (force_tn && tn != force_tn)) continue;
-            const int bm = 16 * tm, bn = 64 * tn;
-            if (bn - 63 > ((g.N + 15) & ~15) && tn != 1) continue;      // wider than the layer
-            const int nsl = (g.N + bn - 1) / bn;
+            if (!force_tn && tn != tn_want) continue;
+            if (!force_tm && tm > (tn_want == 1 ? 8 : 4)) continue;      // measured: 64-pixel tiles from 96 output channels on, 128 below
+            const int bm = 16 * tm;
             for (int TW = 1; TW <= std::min(g.Wo, bm); ++TW) {
                 if (force_tw && TW != force_tw) continue;
                 const int TH = std::min(g.Ho, bm / TW);
@@ -1013,25 +1018,21 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                 const int PH = (TH - 1) * s + 3, PW = (TW - 1) * s + 3;
                 const int n16 = PH * PW * 4, n16p = (n16 + 63) & ~63;
                 if (n16p > 1536) continue;
-                const unsigned lds = xb_lds(tm, tn, n16p);
-                if (lds > 160 * 1024) continue;
-                const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
-                const long wgs = tiles * nsl * max_batch;
-                const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
-                const int per_cu = std::max(1, std::min(4, (int)(160 * 1024 / lds)));
-                const long conc = std::max(1L, std::min<long>(per_cu, (wgs + 255) / 256));
-                const long rounds = (wgs + 256 * conc - 1) / (256 * conc);
-                const double t_dw = ((bm * 4 + 255) / 256) * 700.0, t_mma = tm * tn * 48.0;
-                const double bytes = n16p * 32.0 + 2048 + bn * 128.0;
-                const double t_step = t_dw + t_mma + bytes / 64.0 + 400.0;
-                const double t_wg = g.nk * t_step + 6000.0 + (double)bm * bn * 4 / 24.0;
-                const double cost = rounds * t_wg * (1.0 + 0.45 * (conc - 1)) / (0.5 + 0.5 * cover);
-                if (best < 0 || cost < best) {
-                    best = cost;
-                    *tm_out = tm; *tn_out = tn; *lds_out = lds;
-                    g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p;
-                    g.tiles_x = (g.Wo + TW - 1) / TW;
-                    g.tiles_y = (g.Ho + TH - 1) / TH;
+                for (int db = 0; db <= 1; ++db) {
+                    if (force_db >= 0 ? db != force_db : db != 0) continue;
+                    const unsigned lds = xb_lds(tm, tn, n16p, db);
+                    if (lds > 160 * 1024 || (!forced && lds > 53 * 1024 + 512)) continue;
+                    const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
+                    const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
+                    const double halo = (double)TH * TW * s * s / ((double)PH * PW);       // bytes used / bytes staged
+                    const double score = bm * cover * (0.5 + 0.5 * halo) * (TW >= TH ? 1.0 : 0.999) * ((TW & 3) ? 0.98 : 1.0);
+                    if (score > best) {
+                        best = score;
+                        *tm_out = tm; *tn_out = tn; *lds_out = lds;
+                        g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p; g.db = db;
+                        g.tiles_x = (g.Wo + TW - 1) / TW;
+                        g.tiles_y = (g.Ho + TH - 1) / TH;
+                    }
                 }
             }
         }
@@ -1149,6 +1150,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     std::vector<int> dw_of(n_ops, -1);
     std::vector<xfuse> fuse(n_ops);
     std::vector<char> gone(n_tensors, 0);
+    int n_fused_seen = 0;
     if (!yk_dev_env("YK_X_NOFUSE"))
         for (int i = 0; i + 1 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
@@ -1168,8 +1170,9 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             // is faster (28 vs 39 us, 34 vs 60 us): too few workgroups to hide the fused pipeline's per-step DMA round trips
             // (the rule looks at the image only, not at max_batch: whether a block is fused changes its rounding, and an image's
             // results must not depend on how many images the plan was built for)
-            if (f.g.Ho * f.g.Wo < 128 && !yk_dev_env("YK_XB_ALWAYS")) continue;
-            if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch)) continue;
+            // and up to 192 input channels: from 384 on the two-launch form ties or wins (39.8 vs 44 us at 14x20x384)
+            if ((f.g.Ho * f.g.Wo < 128 || f.g.nk > 6) && !yk_dev_env("YK_XB_ALWAYS")) continue;
+            if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch, n_fused_seen++)) continue;
             dw_of[i + 1] = i;
             skip[i] = 1;
             gone[y] = 1;
@@ -1379,7 +1382,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 yk_set_error("op %d: output tensor not allocated", i);
                 return fail(YK_ERR_UNSUPPORTED);
             }
-            snprintf(nm, sizeof nm, "x:dw3x3s%d+conv1x1_%dto%d%s[%dx%dpx,%dch]", g.stride, cin, co, g.res.p ? "+add" : "", g.TH, g.TW, 64 * l.tn);
+            snprintf(nm, sizeof nm, "x:dw3x3s%d+conv1x1_%dto%d%s[%dx%dpx,%dch,%dstage]", g.stride, cin, co, g.res.p ? "+add" : "", g.TH, g.TW, 64 * l.tn, g.db ? 2 : 1);
             l.flops = 2.0 * Y.h * Y.w * (double)cin * co + 2.0 * Y.h * Y.w * 9 * cin;
             l.bytes = ((double)S.h * S.w * S.c + (double)Y.h * Y.w * co) * 4;
         } else if (ty == YK_OP_CONV) {

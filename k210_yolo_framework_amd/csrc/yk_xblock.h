@@ -38,6 +38,7 @@ struct xb_args {
     uint32_t *amax_out;
     // geometry, fixed at plan creation
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
+    int db;                            // 1: two stages of (patch, parameters, weight tile), DMA(k+1) requested at the start of step k
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw;
     int dbg;
     long long *stamps;                 // developer builds: per-workgroup phase timestamps [wg][16] (wall_clock64), or null
@@ -49,9 +50,9 @@ struct xb_cfg {
     static constexpr int PARB = 2048;                             // 11 x 32 floats = 88 DMA slots of 16 B, deposited by two whole waves (128 slots)
     static constexpr int CPITCH = BN * 4 + 16;
     static constexpr int IPP = (TN >= 3 && TM >= 2) ? (TM + 1) / 2 : TM;   // row blocks per output pass
-    static constexpr int ring(int n16p) { return n16p * 32 + PARB + BN * 128 + BM * 128; }
-    static constexpr int lds(int n16p) {
-        const int r = ring(n16p), ct = IPP * 16 * CPITCH;
+    static constexpr int stage(int n16p) { return n16p * 32 + PARB + BN * 128; }
+    static constexpr int lds(int n16p, int db) {
+        const int r = (db ? 2 : 1) * stage(n16p) + BM * 128, ct = IPP * 16 * CPITCH;
         return (r > ct ? r : ct) + 64;
     }
 };
@@ -65,9 +66,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
 #define XB_STAMP(k) \
     if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)wall_clock64();
     XB_STAMP(0)
-    unsigned char *HI = xsm, *LO = xsm + a.n16p * 16, *PARb = xsm + a.n16p * 32, *Bs = PARb + C::PARB, *A = Bs + BN * 128;
-    const float *PAR = reinterpret_cast<const float *>(PARb);
-    float *sf = reinterpret_cast<float *>(xsm + C::lds(a.n16p) - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
+    const int STG = C::stage(a.n16p);
+    unsigned char *A = xsm + (a.db ? 2 : 1) * STG;
+    float *sf = reinterpret_cast<float *>(xsm + C::lds(a.n16p, a.db) - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
     uint32_t *smax = reinterpret_cast<uint32_t *>(sf + 8);
     // block -> (image, tile); blockIdx.y = N slice
     const int bid = x_xcd_tile(blockIdx.x, gridDim.x);
@@ -106,8 +107,18 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         poff[i] = ok ? (uint32_t)(((iy * a.in.W + ix) * G + (int)g4) * 32) : X_OOB;
     }
     const int g4l = tid & 3;
+    // Workgroups walk the channel steps from different starting points (a function of the tile's place in ITS image only, so an
+    // image's arithmetic does not depend on the batch): 256 CUs asking one L2 for the same weight tile in the same microsecond
+    // serialise on its banks
+    const int rot = (a.dbg & 32) ? 0 : (int)(tl % (uint32_t)a.nk);
+    auto kstep = [&](int i) {
+        const int k = i + rot;
+        return k >= a.nk ? k - a.nk : k;
+    };
     const uint32_t wbase = (uint32_t)(n0 >> 4) * 2048u + lane * 16u, wstep = (uint32_t)a.nslab * 2048u;
-    auto dma_patch = [&](int ks) {                                // patch + depthwise parameters of step ks
+    auto dma_patch = [&](int it_) {                               // patch + depthwise parameters of loop step it_
+        const int ks = kstep(it_);
+        unsigned char *HI = xsm + ((a.db & it_) & 1) * STG, *LO = HI + a.n16p * 16, *PARb = HI + a.n16p * 32;
         const bool gok = (ks * 4 + g4l) < G;
         const uint32_t koff = gok ? (uint32_t)ks * 128u : X_OOB;
 #pragma unroll
@@ -124,7 +135,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr_t)(PARb + wid * 1024), 16, op, 0, 0, 0);
         }
     };
-    auto dma_b = [&](int ks) {                                    // pointwise weight tile of step ks
+    auto dma_b = [&](int it_) {                                   // pointwise weight tile of loop step it_
+        const int ks = kstep(it_);
+        unsigned char *Bs = xsm + ((a.db & it_) & 1) * STG + a.n16p * 32 + C::PARB;
         const uint32_t ws = wbase + (uint32_t)ks * wstep;
 #pragma unroll
         for (int it = 0; it < (BN / 16 * 2 + 3) / 4; ++it) {
@@ -135,7 +148,10 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             }
         }
     };
-    if (!(a.dbg & 1)) dma_patch(0);
+    if (!(a.dbg & 1)) {
+        dma_patch(0);
+        if (a.db) dma_b(0);
+    }
     XB_STAMP(1)
     // per-image factors (one image per workgroup)
     if (wid == 0) {
@@ -171,7 +187,16 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(3) }
-        dma_b(ks);
+        if (a.db) {                                                   // the other stage is free: request all of step ks+1 now
+            if (ks + 1 < nk) {
+                dma_patch(ks + 1);
+                dma_b(ks + 1);
+            }
+        } else {
+            dma_b(ks);
+        }
+        const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16, *Bs = HI + a.n16p * 32 + C::PARB;
+        const float *PAR = reinterpret_cast<const float *>(HI + a.n16p * 32);
         const float up = sf[0], dmid = sf[1];
         // ---- depthwise: item = (pixel p, group q of this step)
         if (!(a.dbg & 2))
@@ -213,11 +238,12 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                 *reinterpret_cast<half8 *>(dst + 1024) = lo;
             }
         if (ks == 0) { XB_STAMP(4) }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                 // the A tile is complete, the weight tile has landed, the patch is free
+        if (a.db) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (step ks+1 stays in flight)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // the A tile is complete (single stage: the weight tile has landed, the patch is free)
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(5) }
-        if (ks + 1 < nk) dma_patch(ks + 1);
+        if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile
         if (!(a.dbg & 16)) {
             half8 xh[TM], xl[TM], wh[TN], wl[TN];
