@@ -264,11 +264,13 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     uint32_t *s_amax = reinterpret_cast<uint32_t *>(s_rup + BM);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    // XCD-aware walk of the 3-D grid, M fastest: neighbouring M tiles (shared halo rows, same weight slice) on one XCD's L2
+    // XCD-aware walk of the 3-D grid
     const int gx = gridDim.x, gy = gridDim.y;
     const int L0 = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const int v = x_xcd_tile(L0, gx * gy * gridDim.z);
-    const int vz = v / (gx * gy), vr = v - vz * (gx * gy), vy = vr / gx, vx = vr - vy * gx;
+    // N tile fastest: the N tiles of one M tile run back to back on one XCD, so the A rows they all read come out of that L2 (with M
+    // fastest a 384 -> 384 pointwise conv fetched its input three times from the fabric: 57 MB for 27.5)
+    const int vz = v / (gx * gy), vr = v - vz * (gx * gy), vx = vr / gy, vy = vr - vx * gy;
     const int m0 = vx * BM, n0 = vy * BN;
     const int b0 = (int)x_div((uint32_t)m0, a.fd_hw), bl = (int)x_div((uint32_t)min(a.M - 1, m0 + BM - 1), a.fd_hw);
     // BatchNorm scale / bias of this lane's channels: requested first, used last (the epilogue would otherwise open with a cold miss)
@@ -317,17 +319,20 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.s1.p ? a.s1.p : a.s0.p), 0, a.s1.p ? a.s1.bytes : a.s0.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
 
-    // walk state (uniform): segment, tap, step inside the tap
+    // walk state (uniform): segment, channel step inside the segment, tap.  The TAP is the fastest index: the nine taps of a channel
+    // step re-read the same 128-byte pieces of neighbouring pixels within nine consecutive steps, i.e. out of L2 / L1 (with the tap as
+    // the outer index a piece came back after a whole pass over the channels and had to be fetched from the fabric again: the 3x3 head
+    // convs moved 25x their algorithmic bytes, profiles/r03_x2_kernel_trace_per_launch.csv first version)
     int step = kt0, seg, tap, cs;
     if (kt0 < kb) {
         seg = 0;
-        tap = kt0 / a.nc0;
-        cs = kt0 - tap * a.nc0;
+        cs = kt0 / a.taps;
+        tap = kt0 - cs * a.taps;
     } else {
         seg = 1;
-        const int r = kt0 - kb, d = max(a.nc1, 1);
-        tap = r / d;
-        cs = r - tap * d;
+        const int r = kt0 - kb;
+        cs = r / a.taps;
+        tap = r - cs * a.taps;
     }
     uint32_t aoff[AR];
     auto retap = [&]() {
@@ -373,16 +378,16 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Bs + (wid * B_IT + it) * 1024), 16, ob, 0, 0, 0);
         }
         ++step;
-        ++cs;
-        if (cs >= nc) {                                            // uniform, once per tap
-            cs = 0;
-            ++tap;
-            if (!seg && tap >= a.taps && a.nc1 > 0) {
+        ++tap;
+        if (tap >= a.taps) {                                       // uniform
+            tap = 0;
+            ++cs;
+            if (!seg && cs >= a.nc0 && a.nc1 > 0) {
                 seg = 1;
-                tap = 0;
+                cs = 0;
             }
-            retap();
         }
+        if (a.taps > 1 || cs == 0) retap();                        // 1x1: the row offsets only change with the segment
     };
     floatx4 acc[TM][TN];
 #pragma unroll
@@ -475,7 +480,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_reduce_kernel(const xg_args a
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid / WN, fr = lane & 15;
     const int gx = gridDim.x, gy = gridDim.y;
     const int v = x_xcd_tile(blockIdx.x + gx * blockIdx.y, gx * gy);
-    const int vy = v / gx, vx = v - vy * gx;
+    const int vx = v / gy, vy = v - vx * gy;
     const int m0 = vx * BM, n0 = vy * BN;
     const int b0 = (int)x_div((uint32_t)m0, a.fd_hw), bl = (int)x_div((uint32_t)min(a.M - 1, m0 + BM - 1), a.fd_hw);
     // BatchNorm scale / bias of this lane's channels: requested first, used last (the epilogue would otherwise open with a cold miss)
@@ -1231,7 +1236,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                     const float wv = blob[o[YK_F_W_OFF] + ((size_t)n * taps + t) * cin + c];
                     const bool second = c >= c0;
                     const int cc = second ? c - c0 : c;
-                    const int step = second ? taps * nc0 + t * nc1 + cc / 32 : t * nc0 + cc / 32;
+                    const int step = second ? taps * nc0 + (cc / 32) * taps + t : (cc / 32) * taps + t;      // channel step outer, tap inner
                     const int k32 = cc % 32, chunk = k32 >> 3, e = k32 & 7, r = n & 15, pos = chunk ^ ((r >> 1) & 3);
                     const float v = ldexpf(wv, sexp);
                     const uint16_t hi = x_f2h(v);
