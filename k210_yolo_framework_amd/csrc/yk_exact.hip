@@ -958,16 +958,27 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
     return YK_ERR_ARG;
 }
 
-template <int TM, int TN>
-int x_launch_b(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+template <int TM, int TN, bool STEM>
+int x_launch_b2(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
     static unsigned allowed = 64 * 1024;
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN, STEM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         allowed = 160 * 1024;
     }
     dim3 grid((unsigned)(batch * g.tiles_x * g.tiles_y), (unsigned)((g.N + 64 * TN - 1) / (64 * TN)));
-    hipLaunchKernelGGL((xb_kernel<TM, TN>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((xb_kernel<TM, TN, STEM>), grid, dim3(256), lds, st, g);
     return YK_OK;
+}
+template <int TM, int TN>
+int x_launch_b(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+    if constexpr (TN == 1) {                                       // the stem-fed block of every network here has <= 64 output channels
+        if (g.stem) return x_launch_b2<TM, TN, true>(g, batch, lds, st);
+    }
+    if (g.stem) {
+        yk_set_error("f16x2: stem fusion needs an N tile of 64");
+        return YK_ERR_UNSUPPORTED;
+    }
+    return x_launch_b2<TM, TN, false>(g, batch, lds, st);
 }
 const int g_xb_tm[] = {2, 3, 4, 5, 8}, g_xb_tn[] = {1, 2, 3, 6};
 bool xb_has(int tm, int tn) {
@@ -1182,6 +1193,25 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             skip[i] = 1;
             gone[y] = 1;
         }
+    // The network's first conv feeding (only) a fused block: computed inside that block's kernel from the frames (yk_xblock.h), its
+    // output tensor is never allocated.  Needs the frame window of a patch to fit in the block's A-tile space.
+    std::vector<int> stem_of(n_ops, -1);
+    if (!yk_dev_env("YK_X_NOSTEMFUSE"))
+        for (int i = 0; i + 2 < n_ops; ++i) {
+            const int32_t *o = ops + (size_t)i * YK_OP_FIELDS;
+            if (o[YK_F_TYPE] != YK_OP_CONV || !p->T[o[YK_F_IN0]].is_input) continue;
+            const int y = o[YK_F_OUT], co = o[YK_F_COUT];
+            const int32_t *d = o + YK_OP_FIELDS;
+            if (d[YK_F_TYPE] != YK_OP_DWCONV || d[YK_F_IN0] != y || dw_of[i + 2] != i + 1 || p->T[y].uses != 1 || o[YK_F_K] != 3 ||
+                (co != 16 && co != 24 && co != 32) || (o[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT))
+                continue;
+            const xfuse &f = fuse[i + 2];
+            const int st = o[YK_F_STRIDE], WR = (f.g.PH - 1) * st + 3, WC = (f.g.PW - 1) * st + 3;
+            if ((size_t)WR * WC * 3 * 4 > (size_t)16 * f.tm * 128 || f.g.nk != 1 || f.tn != 1) continue;
+            stem_of[i + 2] = i;
+            skip[i] = 1;
+            gone[y] = 1;
+        }
     for (int i = 1; i < n_tensors; ++i) {
         xtens &t = p->T[i];
         if (t.kind != XT_REAL || gone[i]) continue;
@@ -1362,6 +1392,59 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             g.in = view_of(sid);
             g.pad_t = dwo[YK_F_PAD_T];
             g.pad_l = dwo[YK_F_PAD_L];
+            double st_flops = 0, st_bytes = 0;
+            char stn[40] = "";
+            if (stem_of[i] >= 0) {
+                const int32_t *so = ops + (size_t)stem_of[i] * YK_OP_FIELDS;
+                const xtens &F = p->T[so[YK_F_IN0]];
+                const int sco = so[YK_F_COUT];
+                float salpha;
+                memcpy(&salpha, &so[YK_F_ALPHA], 4);
+                float gain = 0.f, off = 0.f, wmax = 0.f;
+                for (int c = 0; c < sco; ++c) {
+                    float sw = 0.f;
+                    for (int t = 0; t < 27; ++t) {
+                        const float wv = blob[so[YK_F_W_OFF] + (size_t)c * 27 + t];
+                        sw += fabsf(wv);
+                        wmax = std::max(wmax, fabsf(wv));
+                    }
+                    gain = std::max(gain, sw * fabsf(blob[so[YK_F_SCALE_OFF] + c]));
+                    off = std::max(off, fabsf(blob[so[YK_F_BIAS_OFF] + c]));
+                }
+                // MFMA fragments of the 32 x 32 weight matrix (k = ky*8 + j for the first eight of a filter row's nine values, 24 + ky
+                // for the ninth), w * 2^s = hi + lo
+                const int sexp = (wmax > 0.f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+                std::vector<uint16_t> wf((size_t)2 * 2 * 64 * 8, 0);
+                for (int nf = 0; nf < 2; ++nf)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const int n = nf * 16 + (ln & 15), k = (ln >> 4) * 8 + e;
+                            int t = -1;
+                            if (k < 24) t = (k >> 3) * 9 + (k & 7);            // tap row ky = k/8, j = kx*3 + ci
+                            else if (k < 27) t = (k - 24) * 9 + 8;
+                            if (n >= sco || t < 0) continue;
+                            const float v = ldexpf(blob[so[YK_F_W_OFF] + (size_t)n * 27 + t], sexp);
+                            const uint16_t hi = x_f2h(v);
+                            wf[((size_t)(nf * 2 + 0) * 64 + ln) * 8 + e] = hi;
+                            wf[((size_t)(nf * 2 + 1) * 64 + ln) * 8 + e] = x_f2h(v - x_h2f(hi));
+                        }
+                void *dw_;
+                if ((rc = x_upload(p, &dw_, wf.data(), wf.size() * 2))) return fail(rc);
+                g.stem = 1;
+                g.st_wf = (const yk_half *)dw_;
+                if ((rc = x_upload_f(p, blob + so[YK_F_SCALE_OFF], sco, ldexpf(1.f, -sexp), &g.st_scale))) return fail(rc);
+                if ((rc = x_upload_f(p, blob + so[YK_F_BIAS_OFF], sco, 1.f, &g.st_bias))) return fail(rc);
+                yk_act_params(so[YK_F_ACT], salpha, &g.st_slope, &g.st_cap);
+                g.st_stride = so[YK_F_STRIDE]; g.st_pad_t = so[YK_F_PAD_T]; g.st_pad_l = so[YK_F_PAD_L]; g.st_cout = sco;
+                g.fH = F.h; g.fW = F.w;
+                g.fd_wrow = yk_make_fastdiv((uint32_t)(((g.PW - 1) * g.st_stride + 3) * 3));
+                g.st_bound = std::min(g.st_cap, (gain + off) * 1.0001f);               // the normalised image is in [0, 1]
+                g.st_e = (g.st_bound > 0.f && std::isfinite(g.st_bound)) ? ilogbf(g.st_bound) - 13 : 0;
+                g.in.p = nullptr;                                                       // the tensor does not exist
+                snprintf(stn, sizeof stn, "stem3x3s%d_%d+", g.st_stride, sco);
+                st_flops = 2.0 * S.h * S.w * 27 * sco;
+                st_bytes = (double)F.h * F.w * 3 * 4 + (double)S.h * S.w * sco * 4;
+            }
             if ((rc = pack_dw(dwo, S.c, S.cp, &g.par, &dwgain, &dwoff))) return fail(rc);
             yk_act_params(dwo[YK_F_ACT], dalpha, &g.dw_slope, &g.dw_cap);
             g.dw_gain = dwgain;
@@ -1387,9 +1470,10 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 yk_set_error("op %d: output tensor not allocated", i);
                 return fail(YK_ERR_UNSUPPORTED);
             }
-            snprintf(nm, sizeof nm, "x:dw3x3s%d+conv1x1_%dto%d%s[%dx%dpx,%dch,%dstage]", g.stride, cin, co, g.res.p ? "+add" : "", g.TH, g.TW, 64 * l.tn, g.db ? 2 : 1);
-            l.flops = 2.0 * Y.h * Y.w * (double)cin * co + 2.0 * Y.h * Y.w * 9 * cin;
-            l.bytes = ((double)S.h * S.w * S.c + (double)Y.h * Y.w * co) * 4;
+            snprintf(nm, sizeof nm, "x:%sdw3x3s%d+conv1x1_%dto%d%s[%dx%dpx,%dch,%dstage]", stn, g.stride, cin, co, g.res.p ? "+add" : "", g.TH, g.TW, 64 * l.tn, g.db ? 2 : 1);
+            // algorithmic work of everything this launch replaces, counted unfused: stem + depthwise + pointwise
+            l.flops = 2.0 * Y.h * Y.w * (double)cin * co + 2.0 * Y.h * Y.w * 9 * cin + st_flops;
+            l.bytes = ((double)S.h * S.w * S.c + 2.0 * Y.h * Y.w * cin + (double)Y.h * Y.w * co) * 4 + st_bytes;
         } else if (ty == YK_OP_CONV) {
             l.kind = XK_CONV;
             xg_args &g = l.c;
@@ -1601,6 +1685,11 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
         case XK_BLOCK: {
             xb_args g = l.b;
             g.B = batch;
+            if (g.stem) {
+                g.frames = d_in;
+                g.in_f32 = in_f32;
+                g.img_max = p->d_imgmax;
+            }
             if (const char *e = yk_dev_env("YK_XB_DBG")) g.dbg = atoi(e);
             g.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
             int rc = x_launch_block(l.tm, l.tn, g, batch, l.lds, st);

@@ -40,6 +40,18 @@ struct xb_args {
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
     int db;                            // 1: two stages of (patch, parameters, weight tile), DMA(k+1) requested at the start of step k
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw;
+    // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
+    // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
+    int stem;                          // 0: `in` is a stored tensor
+    const void *frames;                // u8 or f32 [B][fH][fW][3] (set per run)
+    const unsigned *img_max;           // YK_MAXP partial maxima per image (u8 path)
+    int in_f32, fH, fW;
+    int st_stride, st_pad_t, st_pad_l, st_cout;
+    const yk_half *st_wf;              // [2 n-blocks][hi|lo][64 lanes][8]: w * 2^s in MFMA fragment order, k = ky*8+j | 24+ky
+    const float *st_scale, *st_bias;   // [32], zero padded; scale carries 2^-s
+    float st_slope, st_cap, st_bound;  // |stem output| <= st_bound (the normalised image is in [0, 1]); st_e its exponent
+    int st_e;
+    yk_fastdiv fd_wrow;                // division by the window row length (WC * 3)
     int dbg;
     long long *stamps;                 // developer builds: per-workgroup phase timestamps [wg][16] (wall_clock64), or null
 };
@@ -57,7 +69,76 @@ struct xb_cfg {
     }
 };
 
-template <int TM, int TN>
+// The stem conv on the positions of a depthwise patch, on the matrix cores.  K = 27 is padded to 32 in an order chosen for the loader:
+// k = ky*8 + j for the first 8 of the 9 contiguous window values (3 pixels x RGB) a filter row contributes, k = 24 + ky for the ninth,
+// 27..31 zero (`st_wf` holds the weights in that order, split hi | lo, as MFMA fragments).  A lane of the pixel operand (position
+// fr, chunk fq) reads 8 consecutive floats of window row fq (fq < 3) or the three ninth values (fq = 3), splits them and runs three
+// MFMAs per 16 output channels.  Positions outside the stem's output are the depthwise conv's zero padding, not convolutions of padded
+// pixels.  Result: (hi | lo) in the patch layout [position][4 groups of 8 channels].
+__device__ __forceinline__ void xb_stem_patch(const xb_args &a, const float *win, int WC, int iy0, int ix0, unsigned char *HI, unsigned char *LO) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    half8 wfh[2], wfl[2];
+    float4 sc[2], bs[2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+        wfh[nf] = *reinterpret_cast<const half8 *>(a.st_wf + ((size_t)(nf * 2 + 0) * 64 + lane) * 8);
+        wfl[nf] = *reinterpret_cast<const half8 *>(a.st_wf + ((size_t)(nf * 2 + 1) * 64 + lane) * 8);
+        sc[nf] = *reinterpret_cast<const float4 *>(a.st_scale + nf * 16 + fq * 4);
+        bs[nf] = *reinterpret_cast<const float4 *>(a.st_bias + nf * 16 + fq * 4);
+    }
+    const float sdown = x_pow2(-a.st_e);
+    const int st = a.st_stride, npos = a.PH * a.PW, nblk = (npos + 15) >> 4, rowf = WC * 3;
+    for (int blk = wid; blk < nblk; blk += 4) {
+        const int pos = blk * 16 + fr, pc = min(pos, npos - 1);
+        const int r = (int)x_div((uint32_t)pc, a.fd_pw), c = pc - r * a.PW;
+        const bool valid = pos < npos;
+        const bool inside = valid && (unsigned)(iy0 + r) < (unsigned)a.in.H && (unsigned)(ix0 + c) < (unsigned)a.in.W;
+        const float *base = win + ((r * st) * WC + c * st) * 3;
+        float x[8];
+        if (fq < 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = base[fq * rowf + j];
+        } else {
+            x[0] = base[8];
+            x[1] = base[rowf + 8];
+            x[2] = base[2 * rowf + 8];
+#pragma unroll
+            for (int j = 3; j < 8; ++j) x[j] = 0.f;
+        }
+        half8 xh, xl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            yk_half h, l;
+            x_split(x[j], h, l);
+            xh[j] = h;
+            xl[j] = l;
+        }
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[nf], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xh, acc, 0, 0, 0);
+            const float scv[4] = {sc[nf].x, sc[nf].y, sc[nf].z, sc[nf].w}, bsv[4] = {bs[nf].x, bs[nf].y, bs[nf].z, bs[nf].w};
+            half4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = x_actf(acc[k] * scv[k] + bsv[k], a.st_slope, a.st_cap);
+                yk_half h, l;
+                x_split(inside ? v * sdown : 0.f, h, l);
+                hi[k] = h;
+                lo[k] = l;
+            }
+            if (valid) {
+                const int n = nf * 16 + fq * 4, at = (pos * 4 + (n >> 3)) * 16 + (n & 7) * 2;
+                *reinterpret_cast<half4 *>(HI + at) = hi;
+                *reinterpret_cast<half4 *>(LO + at) = lo;
+            }
+        }
+    }
+}
+
+template <int TM, int TN, bool STEM>
 __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb_args a) {   // 2 (3) workgroups per CU: <= 256 (168) registers
     typedef xb_cfg<TM, TN> C;
     constexpr int BM = C::BM, BN = C::BN;
@@ -91,7 +172,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         }
     }
     const uint32_t img = (uint32_t)a.in.H * a.in.W * G * 32u;
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in.p + (size_t)b * img), 0, img, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(STEM ? (const uint8_t *)a.par : a.in.p + (size_t)b * img), 0, STEM ? 16u : img, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void *)a.par, 0, (uint32_t)(11 * G * 32), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     // this lane's patch positions are the same for every step: precompute the source offsets of its (up to PQ) DMA slots
@@ -123,7 +204,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         const uint32_t koff = gok ? (uint32_t)ks * 128u : X_OOB;
 #pragma unroll
         for (int i = 0; i < PQ; ++i)
-            if (i * 256 + wid * 64 < a.n16p) {                    // wave-uniform: n16p is a multiple of 64, a wave deposits 64 slots
+            if (!STEM && i * 256 + wid * 64 < a.n16p) {                    // wave-uniform: n16p is a multiple of 64, a wave deposits 64 slots
                 const uint32_t oh = poff[i] + koff, ol = oh + 16u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(HI + (i * 256 + wid * 64) * 16), 16, oh, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(LO + (i * 256 + wid * 64) * 16), 16, ol, 0, 0, 0);
@@ -152,10 +233,93 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         dma_patch(0);
         if (a.db) dma_b(0);
     }
+    if constexpr (STEM) {
+        // ---- the patch of the depthwise input = the stem conv's output on (PH x PW) positions, straight from the frames.
+        // (1) the frame window those positions need, normalised (`img / np.max(img)`, tools/utils.py:405), as fp32 in LDS (the A tile's
+        //     space: nothing else lives there before the first depthwise pass)
+        const int st = a.st_stride, WR = (a.PH - 1) * st + 3, WC = (a.PW - 1) * st + 3;
+        const int wy0 = iy0 * st - a.st_pad_t, wx0 = ix0 * st - a.st_pad_l;
+        float *win = reinterpret_cast<float *>(A);
+        float inv = 1.f;
+        if (!a.in_f32) {
+            unsigned mx = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) mx = max(mx, a.img_max[b * 32 + j]);
+            inv = (float)mx;
+        }
+        // all of a thread's loads go out before the first one is used, and the u8 / f32 choice is made ONCE outside the unrolled loads
+        // (a load inside a per-element branch makes the compiler drain the memory queue at every join).  u8 frames are fetched four
+        // bytes per lane (unaligned dwords through a buffer descriptor: bytes before the first frame come back as zeros).
+        const int rowf_ = WC * 3;
+        if (a.in_f32) {
+            constexpr int WQ = 16;                                    // window floats per thread: WR*WC*3 <= 16*TM*32 <= WQ*256
+            const float *f = reinterpret_cast<const float *>(a.frames);
+            const size_t fimg = (size_t)b * a.fH * a.fW * 3;
+            float wv[WQ];
+            bool wok[WQ];
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                const int i = q * 256 + tid;
+                const int r = (int)x_div((uint32_t)i, a.fd_wrow), rem = i - r * rowf_, c = rem / 3, ch = rem - c * 3;
+                const int fy = wy0 + r, fx = wx0 + c;
+                wok[q] = i < WR * rowf_ && (unsigned)fy < (unsigned)a.fH && (unsigned)fx < (unsigned)a.fW;
+                wv[q] = f[wok[q] ? fimg + ((size_t)fy * a.fW + fx) * 3 + ch : fimg];
+            }
+#pragma unroll
+            for (int q = 0; q < WQ; ++q) {
+                const int i = q * 256 + tid;
+                if (i < WR * rowf_) win[i] = wok[q] ? wv[q] : 0.f;
+            }
+        } else {
+            constexpr int DQ = 5;                                     // dwords per thread: WR * ceil(WC*3/4) <= DQ*256
+            const int dpr = (rowf_ + 3) >> 2;
+            const uint32_t fbytes = (uint32_t)a.B * a.fH * a.fW * 3u;
+            const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void *)a.frames, 0, fbytes, 0x00020000);
+            const int rowb = a.fW * 3;
+            uint32_t dv[DQ];
+            u32x2 d2[DQ];
+            int sh[DQ];
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                const int i = q * 256 + tid, r = i / dpr, d = i - r * dpr;
+                const int fy = wy0 + r;
+                const bool ok = r < WR && (unsigned)fy < (unsigned)a.fH;
+                // four bytes from a BYTE address (buffer loads ignore the low address bits): the aligned 8 bytes around it, shifted.  The
+                // window may start before / run past its row (masked per byte below); an address below the buffer start (first row of the
+                // first frame, left padding) is read from 0 and shifted the other way
+                const int off = ((int)b * a.fH + fy) * rowb + wx0 * 3 + d * 4;
+                sh[q] = off >= 0 ? (off & 3) * 8 : off * 8;
+                d2[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsf, ok ? (uint32_t)(max(off, 0) & ~3) : X_OOB, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                const unsigned long long v = ((unsigned long long)d2[q][1] << 32) | d2[q][0];
+                dv[q] = sh[q] >= 0 ? (uint32_t)(v >> sh[q]) : (uint32_t)(v << (-sh[q]));
+            }
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                const int i = q * 256 + tid, r = i / dpr, d = i - r * dpr;
+                if (r < WR) {
+                    const bool rowok = (unsigned)(wy0 + r) < (unsigned)a.fH;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int e = d * 4 + k, fxb = wx0 * 3 + e;              // byte column in the frame row
+                        if (e < rowf_) win[r * rowf_ + e] = (rowok && (unsigned)fxb < (unsigned)rowb) ? (float)((dv[q] >> (8 * k)) & 255u) / inv : 0.f;
+                    }
+                }
+            }
+        }
+        XB_STAMP(11)
+        __syncthreads();
+        XB_STAMP(12)
+        // (2) one thread = one patch position, all st_cout channels
+        unsigned char *HI = xsm, *LO = xsm + a.n16p * 16;
+        xb_stem_patch(a, win, WC, iy0, ix0, HI, LO);
+    }
     XB_STAMP(1)
     // per-image factors (one image per workgroup)
     if (wid == 0) {
-        const float amax_in = x_amax_wave(a.in.amax, (int)b);
+        const float amax_in = STEM ? a.st_bound : x_amax_wave(a.in.amax, (int)b);
         const float bmid = fminf(a.dw_cap, a.dw_gain * amax_in + a.dw_off);
         float bout = fminf(a.cap, a.gain * bmid + a.off);
         float rup = 0.f;
@@ -165,7 +329,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         }
         const int em = x_exp_of(__float_as_uint(bmid)), eo = x_exp_of(__float_as_uint(bout));
         if (lane == 0) {
-            sf[0] = x_pow2(a.in.eexp[b]);
+            sf[0] = x_pow2(STEM ? a.st_e : a.in.eexp[b]);
             sf[1] = x_pow2(-em);
             sf[2] = x_pow2(em);
             sf[3] = x_pow2(-eo);

@@ -391,7 +391,9 @@ class Trainer:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: the input pipeline's producer thread allocates pinned / device buffers and copies while this thread
+                # captures; in the default (global) mode any such call from another thread invalidates the capture
+                with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                     self._gres = self.loss_and_grads(self._gx, self._gy)
             cur.wait_stream(side)
             self._graph = g

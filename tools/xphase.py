@@ -34,6 +34,8 @@ for li in [int(v) for v in sys.argv[1].split(',')]:
     for k in range(1, 11):
         print('  %-22s median %6.2f us  p90 %6.2f  max %6.2f   (step %+5.2f)' % (lab[k], np.median(d[:, k]), np.percentile(d[:, k], 90), d[:, k].max(),
                                                                                np.median(d[:, k] - d[:, k - 1])))
+    if v[:, 11].max() > 0:
+        print('  stem: window loads issued+stored %.2f us, barrier %.2f us, patch done (stamp 1) %.2f us' % (np.median(d[:, 11]), np.median(d[:, 12]), np.median(d[:, 1])))
     st = (v[:, 0] - t0) / 100.0
     print('  WG start times: median %.2f p90 %.2f max %.2f us' % (np.median(st), np.percentile(st, 90), st.max()))
 plan.close()
