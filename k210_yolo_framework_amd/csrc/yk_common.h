@@ -19,6 +19,13 @@ static inline const char *yk_dev_env(const char *name) { return getenv(name); }
 static inline const char *yk_dev_env(const char *) { return nullptr; }
 #endif
 
+// the few switches the shipped library does read, at plan creation only (README "Environment switches")
+static inline bool yk_env_flag(const char *name, bool dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    return e[0] != '0';
+}
+
 void yk_set_error(const char *fmt, ...);
 
 #define YK_HIP(call)                                                                           \

@@ -128,11 +128,7 @@ static int upload_sb(yk_plan *p, const float *blob, int off, int n, const float 
     return rc;
 }
 
-static bool env_flag(const char *name, bool dflt) {
-    const char *e = getenv(name);
-    if (!e || !*e) return dflt;
-    return e[0] != '0';
-}
+static bool env_flag(const char *name, bool dflt) { return yk_env_flag(name, dflt); }
 
 extern "C" void yk_plan_destroy(yk_plan_t *p) {
     if (!p) return;

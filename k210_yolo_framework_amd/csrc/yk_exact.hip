@@ -1167,7 +1167,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     std::vector<xfuse> fuse(n_ops);
     std::vector<char> gone(n_tensors, 0);
     int n_fused_seen = 0;
-    if (!yk_dev_env("YK_X_NOFUSE"))
+    const bool fuse_blocks = yk_env_flag("YK_FUSE_DWPW", true) && !yk_dev_env("YK_X_NOFUSE");
+    if (fuse_blocks)
         for (int i = 0; i + 1 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
             const int y = o[YK_F_OUT];
@@ -1196,7 +1197,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     // The network's first conv feeding (only) a fused block: computed inside that block's kernel from the frames (yk_xblock.h), its
     // output tensor is never allocated.  Needs the frame window of a patch to fit in the block's A-tile space.
     std::vector<int> stem_of(n_ops, -1);
-    if (!yk_dev_env("YK_X_NOSTEMFUSE"))
+    if (fuse_blocks && !yk_dev_env("YK_X_NOSTEMFUSE"))
         for (int i = 0; i + 2 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS;
             if (o[YK_F_TYPE] != YK_OP_CONV || !p->T[o[YK_F_IN0]].is_input) continue;
@@ -1532,6 +1533,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 long sk = 1;
                 if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(8, (640 + tiles - 1) / tiles), nsteps / 8);
+                if (!yk_env_flag("YK_SPLITK", true)) sk = 1;
                 if (const char *e = yk_dev_env("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nsteps));
                 g.splitk = (int)std::max<long>(1, sk);
                 if (g.splitk > 1) {

@@ -25,10 +25,11 @@ TOL_EMU = 1.5e-2
 TOL_F32 = 3e-2
 
 
-def _run_plan(spec, w, x_u8=None, x_f32=None, fuse=True, want=(), precision='f16'):
+def _run_plan(spec, w, x_u8=None, x_f32=None, fuse=True, want=(), precision='f16', splitk=True):
     import torch
     from k210_yolo_framework_amd import engine
     os.environ['YK_FUSE_DWPW'] = '1' if fuse else '0'
+    os.environ['YK_SPLITK'] = '1' if splitk else '0'
     B = (x_u8 if x_u8 is not None else x_f32).shape[0]
     plan = engine.Plan(spec, w, max_batch=B, precision=precision)
     if x_u8 is not None:
@@ -155,11 +156,14 @@ TOL_X2_V2 = 5e-4       # undamped MobileNet-v2 amplifies ANY perturbation ~1.5x 
 #                        summation-order noise included - two fp32 implementations differ by this much; measured 1.1e-4
 
 
-@pytest.mark.parametrize('name,shape,alpha,B,u8', [
-    ('yolo_mobilev1', (224, 320, 3), 0.75, 2, True), ('yolo_mobilev1', (96, 64, 3), 0.5, 3, True),
-    ('yolo_mobilev2', (224, 320, 3), 1.0, 2, True), ('yolo_mobilev2', (64, 96, 3), 0.75, 1, True),
-    ('tiny_yolo', (416, 416, 3), 1.0, 1, False), ('yolo', (96, 128, 3), 1.0, 2, False), ('yolo', (416, 416, 3), 1.0, 1, False)])
-def test_f16x2_whole_network_undamped_vs_fp32_oracle(name, shape, alpha, B, u8):
+@pytest.mark.parametrize('name,shape,alpha,B,u8,fuse', [
+    ('yolo_mobilev1', (224, 320, 3), 0.75, 2, True, True), ('yolo_mobilev1', (96, 64, 3), 0.5, 3, True, True),
+    ('yolo_mobilev1', (224, 320, 3), 0.75, 2, True, False),     # YK_FUSE_DWPW=0 YK_SPLITK=0: stem / depthwise / 1x1 as separate launches
+    ('yolo_mobilev2', (224, 320, 3), 1.0, 2, True, True), ('yolo_mobilev2', (64, 96, 3), 0.75, 1, True, True),
+    ('yolo_mobilev2', (64, 96, 3), 0.75, 2, True, False),
+    ('tiny_yolo', (416, 416, 3), 1.0, 1, False, True), ('yolo', (96, 128, 3), 1.0, 2, False, True),
+    ('yolo', (416, 416, 3), 1.0, 1, False, True)])
+def test_f16x2_whole_network_undamped_vs_fp32_oracle(name, shape, alpha, B, u8, fuse):
     """No gamma damping anywhere: MobileNet-v2 saturates its ReLU6s, Darknet-53's 23 residual adds drive activations to ~1e6 (past the
     fp16 range - the f16 plan returns inf here); the compensated operands with per-image exponents follow the fp32 path regardless."""
     spec = ns.NETWORKS[name](shape, 3, 20, alpha=alpha)
@@ -168,8 +172,10 @@ def test_f16x2_whole_network_undamped_vs_fp32_oracle(name, shape, alpha, B, u8):
     x = oracle.normalise_u8(frames)
     every = [op['out'] for op in spec.ops if op['type'] in (ns.OP_CONV, ns.OP_DWCONV, ns.OP_ADD, ns.OP_MAXPOOL)]
     pick = every[::max(1, len(every) // 6)]     # each picked tensor costs one pass of the CPU oracle
-    outs, mids, names = _run_plan(spec, w, x_u8=frames if u8 else None, x_f32=None if u8 else x, want=pick, precision='f16x2')
+    outs, mids, names = _run_plan(spec, w, x_u8=frames if u8 else None, x_f32=None if u8 else x, want=pick, precision='f16x2',
+                                  fuse=fuse, splitk=fuse)
     assert all(n.startswith('x:') or n == 'u8_max' for n in names)
+    assert fuse or not any('+conv' in n or '+dw' in n or 'splitk' in n for n in names), names
     tol = TOL_X2_V2 if name == 'yolo_mobilev2' else TOL_X2
     plan = spec.compile_plan(w)
     for t, got in mids.items():
