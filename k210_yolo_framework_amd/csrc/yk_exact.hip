@@ -99,9 +99,47 @@ __device__ __forceinline__ void x_fma_mix_lo(float &acc, uint32_t a, float w) {
 __device__ __forceinline__ void x_fma_mix_hi(float &acc, uint32_t a, float w) {
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(a), "v"(w));
 }
+// f16(lo | hi halves of h) + f16(same half of l) as fp32: the stored pair (hi, lo) of one channel back in one register, one VALU op
+__device__ __forceinline__ float x_mix_sum_lo(uint32_t h, uint32_t l) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+__device__ __forceinline__ float x_mix_sum_hi(uint32_t h, uint32_t l) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x_split(float s, yk_half &hi, yk_half &lo) {
     hi = (yk_half)s;
     lo = (yk_half)(s - (float)hi);
+}
+// the same split for a pair: one packed conversion per half pair, the residual s - hi (exact in fp32) by one mixed-precision op that reads
+// hi straight out of the packed register - 2 VALU ops per value instead of 4, bit-identical results
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x_split2(float a, float b, uint32_t &hi2, uint32_t &lo2) {
+    const half2v h = {(_Float16)a, (_Float16)b};
+    hi2 = __builtin_bit_cast(uint32_t, h);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi2), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi2), "v"(b));
+    const half2v l = {(_Float16)ra, (_Float16)rb};
+    lo2 = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void x_split4(const float *v, half4 &hi, half4 &lo) {
+    uint32_t h0, h1, l0, l1;
+    x_split2(v[0], v[1], h0, l0);
+    x_split2(v[2], v[3], h1, l1);
+    hi = __builtin_bit_cast(half4, u32x2{h0, h1});
+    lo = __builtin_bit_cast(half4, u32x2{l0, l1});
+}
+__device__ __forceinline__ void x_split8(const float *v, half8 &hi, half8 &lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x_split2(v[2 * j], v[2 * j + 1], h[j], l[j]);
+    hi = __builtin_bit_cast(half8, u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(half8, u32x4{l[0], l[1], l[2], l[3]});
 }
 
 // =====================================================================================================================
@@ -199,10 +237,10 @@ __device__ __forceinline__ void xg_epilogue(const xg_args &a, floatx4 (&acc)[BM 
         for (int j = 0; j < C::TN; ++j) {
             const int nl = (wn * C::TN + j) * 16 + nl4, n = n0 + nl;
             float v[4];
-            v[0] = x_actf(acc[i][j][0] * up * sc[j].x + bs[j].x, a.slope, a.cap);
-            v[1] = x_actf(acc[i][j][1] * up * sc[j].y + bs[j].y, a.slope, a.cap);
-            v[2] = x_actf(acc[i][j][2] * up * sc[j].z + bs[j].z, a.slope, a.cap);
-            v[3] = x_actf(acc[i][j][3] * up * sc[j].w + bs[j].w, a.slope, a.cap);
+            v[0] = x_actf(__builtin_fmaf(acc[i][j][0] * up, sc[j].x, bs[j].x), a.slope, a.cap);
+            v[1] = x_actf(__builtin_fmaf(acc[i][j][1] * up, sc[j].y, bs[j].y), a.slope, a.cap);
+            v[2] = x_actf(__builtin_fmaf(acc[i][j][2] * up, sc[j].z, bs[j].z), a.slope, a.cap);
+            v[3] = x_actf(__builtin_fmaf(acc[i][j][3] * up, sc[j].w, bs[j].w), a.slope, a.cap);
             if (a.out32) {
                 if (mok) {
                     float *o = a.out32 + (size_t)m * a.N + n;
@@ -219,14 +257,13 @@ __device__ __forceinline__ void xg_epilogue(const xg_args &a, floatx4 (&acc)[BM 
                 for (int k = 0; k < 4; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * rup;
             }
             half4 hi, lo;
+            float vd[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (mok) rmax = fmaxf(rmax, fabsf(v[k]));
-                yk_half h, l;
-                x_split(v[k] * down, h, l);
-                hi[k] = h;
-                lo[k] = l;
+                vd[k] = v[k] * down;
             }
+            x_split4(vd, hi, lo);
             unsigned char *d = Cs + r * C::CPITCH + (nl >> 3) * 32 + (nl & 7) * 2;
             *reinterpret_cast<half4 *>(d) = hi;
             *reinterpret_cast<half4 *>(d + 16) = lo;
@@ -598,25 +635,28 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
             const int oy = oy0 + py, ox = ox0 + px;
             if (oy >= a.Ho || ox >= a.Wo) continue;
             const int base = ((py * s) * a.PW + px * s) * a.GS + gl;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float2v acc2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int at = (base + ((t / 3) * a.PW + (t % 3)) * a.GS) * 16;
-                const half8 h = *reinterpret_cast<const half8 *>(HI + at), l = *reinterpret_cast<const half8 *>(LO + at);
-                const float w[8] = {w0[t].x, w0[t].y, w0[t].z, w0[t].w, w1[t].x, w1[t].y, w1[t].z, w1[t].w};
+                const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
+                const float2v w2[4] = {{w0[t].x, w0[t].y}, {w0[t].z, w0[t].w}, {w1[t].x, w1[t].y}, {w1[t].z, w1[t].w}};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)h[j] + (float)l[j], w[j], acc[j]);
+                for (int j = 0; j < 4; ++j) {                    // hi + lo back in fp32 (one op per channel), packed fp32 FMA on channel pairs
+                    const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
+                    acc2[j] = __builtin_elementwise_fma(x2, w2[j], acc2[j]);
+                }
             }
+            const float acc[8] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
             half8 hi, lo;
+            float vd[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = x_actf(acc[j] * sc[j] + bs[j], a.slope, a.cap);
+                const float v = x_actf(__builtin_fmaf(acc[j], sc[j], bs[j]), a.slope, a.cap);
                 mx = fmaxf(mx, fabsf(v));
-                yk_half h, l;
-                x_split(v * down, h, l);
-                hi[j] = h;
-                lo[j] = l;
+                vd[j] = v * down;
             }
+            x_split8(vd, hi, lo);
             uint8_t *o = a.out + ((((size_t)b * a.Ho + oy) * a.Wo + ox) * G + g0 + gl) * 32;
             if (a.dbg & 4) continue;
             *reinterpret_cast<half8 *>(o) = hi;
@@ -1439,6 +1479,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 g.st_stride = so[YK_F_STRIDE]; g.st_pad_t = so[YK_F_PAD_T]; g.st_pad_l = so[YK_F_PAD_L]; g.st_cout = sco;
                 g.fH = F.h; g.fW = F.w;
                 g.fd_wrow = yk_make_fastdiv((uint32_t)(((g.PW - 1) * g.st_stride + 3) * 3));
+                g.fd_dpr = yk_make_fastdiv((uint32_t)((((g.PW - 1) * g.st_stride + 3) * 3 + 3) / 4));
                 g.st_bound = std::min(g.st_cap, (gain + off) * 1.0001f);               // the normalised image is in [0, 1]
                 g.st_e = (g.st_bound > 0.f && std::isfinite(g.st_bound)) ? ilogbf(g.st_bound) - 13 : 0;
                 g.in.p = nullptr;                                                       // the tensor does not exist

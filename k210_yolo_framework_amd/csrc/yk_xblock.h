@@ -52,6 +52,7 @@ struct xb_args {
     float st_slope, st_cap, st_bound;  // |stem output| <= st_bound (the normalised image is in [0, 1]); st_e its exponent
     int st_e;
     yk_fastdiv fd_wrow;                // division by the window row length (WC * 3)
+    yk_fastdiv fd_dpr;                 // division by the window row length in dwords (u8 frames: the window stays bytes in LDS)
     int dbg;
     long long *stamps;                 // developer builds: per-workgroup phase timestamps [wg][16] (wall_clock64), or null
 };
@@ -75,60 +76,85 @@ struct xb_cfg {
 // fr, chunk fq) reads 8 consecutive floats of window row fq (fq < 3) or the three ninth values (fq = 3), splits them and runs three
 // MFMAs per 16 output channels.  Positions outside the stem's output are the depthwise conv's zero padding, not convolutions of padded
 // pixels.  Result: (hi | lo) in the patch layout [position][4 groups of 8 channels].
-__device__ __forceinline__ void xb_stem_patch(const xb_args &a, const float *win, int WC, int iy0, int ix0, unsigned char *HI, unsigned char *LO) {
+// u8 frames (U8): the window is BYTES in LDS (row pitch `pitch`, a multiple of 4); a lane fetches the three aligned dwords around its
+// 8 bytes and shifts them into place (v_alignbyte).  A byte is exact in fp16, so the pixel operand has no low half and the division of
+// `img / np.max(img)` (tools/utils.py:405) moves behind the sum: conv(img) * (scale / max) in fp32 - two MFMAs per tile instead of
+// three, no per-pixel split.  f32 frames: the window is fp32, already normalised by the caller; the operand is split as everywhere.
+// The storage exponent of the stem's output is a plan constant (the image is in [0, 1]), folded into scale, bias and cap.
+template <bool U8>
+__device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp, int WC, int pitch, float inv, int iy0, int ix0, unsigned char *HI, unsigned char *LO) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     half8 wfh[2], wfl[2];
-    float4 sc[2], bs[2];
+    float scv[2][4], bsv[2][4];
+    const float sdown = x_pow2(-a.st_e), sfac = U8 ? sdown / inv : sdown, cap = a.st_cap * sdown;
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
         wfh[nf] = *reinterpret_cast<const half8 *>(a.st_wf + ((size_t)(nf * 2 + 0) * 64 + lane) * 8);
         wfl[nf] = *reinterpret_cast<const half8 *>(a.st_wf + ((size_t)(nf * 2 + 1) * 64 + lane) * 8);
-        sc[nf] = *reinterpret_cast<const float4 *>(a.st_scale + nf * 16 + fq * 4);
-        bs[nf] = *reinterpret_cast<const float4 *>(a.st_bias + nf * 16 + fq * 4);
+        const float4 sc = *reinterpret_cast<const float4 *>(a.st_scale + nf * 16 + fq * 4);
+        const float4 bs = *reinterpret_cast<const float4 *>(a.st_bias + nf * 16 + fq * 4);
+        scv[nf][0] = sc.x * sfac, scv[nf][1] = sc.y * sfac, scv[nf][2] = sc.z * sfac, scv[nf][3] = sc.w * sfac;
+        bsv[nf][0] = bs.x * sdown, bsv[nf][1] = bs.y * sdown, bsv[nf][2] = bs.z * sdown, bsv[nf][3] = bs.w * sdown;
     }
-    const float sdown = x_pow2(-a.st_e);
     const int st = a.st_stride, npos = a.PH * a.PW, nblk = (npos + 15) >> 4, rowf = WC * 3;
     for (int blk = wid; blk < nblk; blk += 4) {
         const int pos = blk * 16 + fr, pc = min(pos, npos - 1);
         const int r = (int)x_div((uint32_t)pc, a.fd_pw), c = pc - r * a.PW;
         const bool valid = pos < npos;
         const bool inside = valid && (unsigned)(iy0 + r) < (unsigned)a.in.H && (unsigned)(ix0 + c) < (unsigned)a.in.W;
-        const float *base = win + ((r * st) * WC + c * st) * 3;
-        float x[8];
-        if (fq < 3) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = base[fq * rowf + j];
-        } else {
-            x[0] = base[8];
-            x[1] = base[rowf + 8];
-            x[2] = base[2 * rowf + 8];
-#pragma unroll
-            for (int j = 3; j < 8; ++j) x[j] = 0.f;
-        }
         half8 xh, xl;
+        if constexpr (U8) {
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>(winp);
+            const int off = (r * st) * pitch + c * st * 3;
+            uint32_t d0, d1 = 0u;
+            if (fq < 3) {
+                const int o = off + fq * pitch, sh = o & 3;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(wb + (o & ~3));
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+                d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            } else {
+                d0 = (uint32_t)wb[off + 8] | ((uint32_t)wb[off + pitch + 8] << 8) | ((uint32_t)wb[off + 2 * pitch + 8] << 16);
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            yk_half h, l;
-            x_split(x[j], h, l);
-            xh[j] = h;
-            xl[j] = l;
+            for (int j = 0; j < 4; ++j) {
+                xh[j] = (yk_half)(float)((d0 >> (8 * j)) & 255u);
+                xh[4 + j] = (yk_half)(float)((d1 >> (8 * j)) & 255u);
+            }
+        } else {
+            const float *base = reinterpret_cast<const float *>(winp) + ((r * st) * WC + c * st) * 3;
+            float x[8];
+            if (fq < 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = base[fq * rowf + j];
+            } else {
+                x[0] = base[8];
+                x[1] = base[rowf + 8];
+                x[2] = base[2 * rowf + 8];
+#pragma unroll
+                for (int j = 3; j < 8; ++j) x[j] = 0.f;
+            }
+            x_split8(x, xh, xl);
         }
+        floatx4 acc[2];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[nf], xh, floatx4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if constexpr (!U8) {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xl, acc[nf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xh, acc[nf], 0, 0, 0);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfl[nf], xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xh, acc, 0, 0, 0);
-            const float scv[4] = {sc[nf].x, sc[nf].y, sc[nf].z, sc[nf].w}, bsv[4] = {bs[nf].x, bs[nf].y, bs[nf].z, bs[nf].w};
             half4 hi, lo;
+            float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float v = x_actf(acc[k] * scv[k] + bsv[k], a.st_slope, a.st_cap);
-                yk_half h, l;
-                x_split(inside ? v * sdown : 0.f, h, l);
-                hi[k] = h;
-                lo[k] = l;
+                const float u = __builtin_fmaf(acc[nf][k], scv[nf][k], bsv[nf][k]);
+                v[k] = inside ? fminf(fmaxf(u, u * a.st_slope), cap) : 0.f;
             }
+            x_split4(v, hi, lo);
             if (valid) {
                 const int n = nf * 16 + fq * 4, at = (pos * 4 + (n >> 3)) * 16 + (n & 7) * 2;
                 *reinterpret_cast<half4 *>(HI + at) = hi;
@@ -276,45 +302,41 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             const uint32_t fbytes = (uint32_t)a.B * a.fH * a.fW * 3u;
             const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void *)a.frames, 0, fbytes, 0x00020000);
             const int rowb = a.fW * 3;
-            uint32_t dv[DQ];
             u32x2 d2[DQ];
             int sh[DQ];
+            uint32_t msk[DQ];
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
-                const int i = q * 256 + tid, r = i / dpr, d = i - r * dpr;
+                const int i = q * 256 + tid, r = (int)x_div((uint32_t)i, a.fd_dpr), d = i - r * dpr;
                 const int fy = wy0 + r;
                 const bool ok = r < WR && (unsigned)fy < (unsigned)a.fH;
                 // four bytes from a BYTE address (buffer loads ignore the low address bits): the aligned 8 bytes around it, shifted.  The
-                // window may start before / run past its row (masked per byte below); an address below the buffer start (first row of the
+                // window may start before / run past its row (masked per byte); an address below the buffer start (first row of the
                 // first frame, left padding) is read from 0 and shifted the other way
-                const int off = ((int)b * a.fH + fy) * rowb + wx0 * 3 + d * 4;
+                const int col = wx0 * 3 + d * 4;                          // byte column of this dword's first byte in the frame row
+                const int off = ((int)b * a.fH + fy) * rowb + col;
                 sh[q] = off >= 0 ? (off & 3) * 8 : off * 8;
                 d2[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsf, ok ? (uint32_t)(max(off, 0) & ~3) : X_OOB, 0, 0));
+                const int lo = max(0, -col), hi = min(4, rowb - col);      // bytes [lo, hi) of the dword lie inside the frame row
+                msk[q] = (ok && hi > lo) ? ((0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * (4 - hi)))) : 0u;
             }
 #pragma unroll
             for (int q = 0; q < DQ; ++q) {
+                const int i = q * 256 + tid;
                 const unsigned long long v = ((unsigned long long)d2[q][1] << 32) | d2[q][0];
-                dv[q] = sh[q] >= 0 ? (uint32_t)(v >> sh[q]) : (uint32_t)(v << (-sh[q]));
+                const uint32_t dv = sh[q] >= 0 ? (uint32_t)(v >> sh[q]) : (uint32_t)(v << (-sh[q]));
+                if (i < WR * dpr) reinterpret_cast<uint32_t *>(A)[i] = dv & msk[q];
             }
-#pragma unroll
-            for (int q = 0; q < DQ; ++q) {
-                const int i = q * 256 + tid, r = i / dpr, d = i - r * dpr;
-                if (r < WR) {
-                    const bool rowok = (unsigned)(wy0 + r) < (unsigned)a.fH;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = d * 4 + k, fxb = wx0 * 3 + e;              // byte column in the frame row
-                        if (e < rowf_) win[r * rowf_ + e] = (rowok && (unsigned)fxb < (unsigned)rowb) ? (float)((dv[q] >> (8 * k)) & 255u) / inv : 0.f;
-                    }
-                }
-            }
+            // the patch builder reads whole dwords: up to 11 bytes past a row's last value -> two dwords past the window's end
+            if (tid < 2) reinterpret_cast<uint32_t *>(A)[WR * dpr + tid] = 0u;
         }
         XB_STAMP(11)
         __syncthreads();
         XB_STAMP(12)
         // (2) one thread = one patch position, all st_cout channels
         unsigned char *HI = xsm, *LO = xsm + a.n16p * 16;
-        xb_stem_patch(a, win, WC, iy0, ix0, HI, LO);
+        if (a.in_f32) xb_stem_patch<false>(a, A, WC, 0, 1.f, iy0, ix0, HI, LO);
+        else xb_stem_patch<true>(a, A, WC, ((WC * 3 + 3) >> 2) * 4, inv, iy0, ix0, HI, LO);
     }
     XB_STAMP(1)
     // per-image factors (one image per workgroup)
@@ -371,30 +393,27 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                 half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
                 if (live) {
                     const int base = ((py * s) * a.PW + px * s) * 4 + q;
-                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    // x = hi + lo back in fp32 by one mixed-precision op per channel, then packed fp32 FMAs (two channels per
+                    // instruction): 12 VALU ops per tap and channel group instead of 16
+                    float2v d2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int at = (base + ((t / 3) * a.PW + (t % 3)) * 4) * 16;
                         const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
                         const float4 w0 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8), w1 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8 + 4);
-                        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                        const float2v w2[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {                 // x = hi + lo: two mixed-precision FMAs, no conversions
-                            x_fma_mix_lo(d[2 * j], h[j], w[2 * j]);
-                            x_fma_mix_lo(d[2 * j], l[j], w[2 * j]);
-                            x_fma_mix_hi(d[2 * j + 1], h[j], w[2 * j + 1]);
-                            x_fma_mix_hi(d[2 * j + 1], l[j], w[2 * j + 1]);
+                        for (int j = 0; j < 4; ++j) {
+                            const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
+                            d2[j] = __builtin_elementwise_fma(x2, w2[j], d2[j]);
                         }
                     }
+                    const float d[8] = {d2[0].x, d2[0].y, d2[1].x, d2[1].y, d2[2].x, d2[2].y, d2[3].x, d2[3].y};
                     const float *scd = PAR + 9 * 32 + q * 8, *bsd = PAR + 10 * 32 + q * 8;
+                    float vd[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float v = x_actf(d[j] * up * scd[j] + bsd[j], a.dw_slope, a.dw_cap);
-                        yk_half h, l;
-                        x_split(v * dmid, h, l);
-                        hi[j] = h;
-                        lo[j] = l;
-                    }
+                    for (int j = 0; j < 8; ++j) vd[j] = x_actf(__builtin_fmaf(d[j] * up, scd[j], bsd[j]), a.dw_slope, a.dw_cap) * dmid;
+                    x_split8(vd, hi, lo);
                 }
                 const int r = p & 15;
                 unsigned char *dst = A + (p >> 4) * 2048 + r * 64 + ((q ^ ((r >> 1) & 3)) * 16);
@@ -454,6 +473,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             bs[j] = *reinterpret_cast<const float4 *>(a.bias + n);
         }
     }
+    float4 scu[TN];                                                   // BN scale with the middle exponent folded in (a power of two: exact)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) scu[j] = float4{sc[j].x * umid, sc[j].y * umid, sc[j].z * umid, sc[j].w * umid};
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += IPP) {
         if (i0 > 0) __syncthreads();                                  // the previous pass has been copied out
@@ -468,10 +490,10 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             for (int j = 0; j < TN; ++j) {
                 const int nl = (wid * TN + j) * 16 + nl4, n = n0 + nl;
                 float v[4];
-                v[0] = x_actf(acc[i][j][0] * umid * sc[j].x + bs[j].x, a.slope, a.cap);
-                v[1] = x_actf(acc[i][j][1] * umid * sc[j].y + bs[j].y, a.slope, a.cap);
-                v[2] = x_actf(acc[i][j][2] * umid * sc[j].z + bs[j].z, a.slope, a.cap);
-                v[3] = x_actf(acc[i][j][3] * umid * sc[j].w + bs[j].w, a.slope, a.cap);
+                v[0] = x_actf(__builtin_fmaf(acc[i][j][0], scu[j].x, bs[j].x), a.slope, a.cap);
+                v[1] = x_actf(__builtin_fmaf(acc[i][j][1], scu[j].y, bs[j].y), a.slope, a.cap);
+                v[2] = x_actf(__builtin_fmaf(acc[i][j][2], scu[j].z, bs[j].z), a.slope, a.cap);
+                v[3] = x_actf(__builtin_fmaf(acc[i][j][3], scu[j].w, bs[j].w), a.slope, a.cap);
                 if (a.res.p && mok && (n >> 3) < a.res.G) {
                     const uint8_t *q = a.res.p + (m * a.res.G + (n >> 3)) * 32 + (n & 7) * 2;
                     const half4 rh = *reinterpret_cast<const half4 *>(q), rl = *reinterpret_cast<const half4 *>(q + 16);
@@ -479,14 +501,13 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                     for (int k = 0; k < 4; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * rup;
                 }
                 half4 hi, lo;
+                float vd[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (mok) rmax = fmaxf(rmax, fabsf(v[k]));
-                    yk_half h, l;
-                    x_split(v[k] * dout, h, l);
-                    hi[k] = h;
-                    lo[k] = l;
+                    vd[k] = v[k] * dout;
                 }
+                x_split4(vd, hi, lo);
                 unsigned char *d = Cs + (p - i0 * 16) * C::CPITCH + (nl >> 3) * 32 + (nl & 7) * 2;
                 *reinterpret_cast<half4 *>(d) = hi;
                 *reinterpret_cast<half4 *>(d + 16) = lo;
