@@ -1097,6 +1097,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
     g.fd_tx = yk_make_fastdiv((uint32_t)g.tiles_x);
     g.fd_tw = yk_make_fastdiv((uint32_t)g.TW);
     g.fd_pw = yk_make_fastdiv((uint32_t)g.PW);
+    g.fd_nk = yk_make_fastdiv((uint32_t)std::max(1, g.nk));
     return true;
 }
 

@@ -39,7 +39,7 @@ struct xb_args {
     // geometry, fixed at plan creation
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
     int db;                            // 1: two stages of (patch, parameters, weight tile), DMA(k+1) requested at the start of step k
-    yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw;
+    yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw, fd_nk;
     // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
     // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
     int stem;                          // 0: `in` is a stored tensor
@@ -170,8 +170,12 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     constexpr int BM = C::BM, BN = C::BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = a.in.G, s = a.stride;
+#ifdef YK_DEV
 #define XB_STAMP(k) \
     if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)wall_clock64();
+#else
+#define XB_STAMP(k)
+#endif
     XB_STAMP(0)
     const int STG = C::stage(a.n16p);
     unsigned char *A = xsm + (a.db ? 2 : 1) * STG;
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     // Workgroups walk the channel steps from different starting points (a function of the tile's place in ITS image only, so an
     // image's arithmetic does not depend on the batch): 256 CUs asking one L2 for the same weight tile in the same microsecond
     // serialise on its banks
-    const int rot = (a.dbg & 32) ? 0 : (int)(tl % (uint32_t)a.nk);
+    const int rot = (a.nk == 1 || (a.dbg & 32)) ? 0 : (int)(tl - x_div(tl, a.fd_nk) * (uint32_t)a.nk);
     auto kstep = [&](int i) {
         const int k = i + rot;
         return k >= a.nk ? k - a.nk : k;
@@ -382,7 +386,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             dma_b(ks);
         }
         const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16, *Bs = HI + a.n16p * 32 + C::PARB;
-        const float *PAR = reinterpret_cast<const float *>(HI + a.n16p * 32);
+        // the parameter slice is read as DWORDS, like the patch: a float-typed LDS read makes the compiler wait for every LDS-DMA in
+        // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
+        const unsigned char *PARB_ = HI + a.n16p * 32;
         const float up = sf[0], dmid = sf[1];
         // ---- depthwise: item = (pixel p, group q of this step)
         if (!(a.dbg & 2))
@@ -400,8 +406,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                     for (int t = 0; t < 9; ++t) {
                         const int at = (base + ((t / 3) * a.PW + (t % 3)) * 4) * 16;
                         const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
-                        const float4 w0 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8), w1 = *reinterpret_cast<const float4 *>(PAR + t * 32 + q * 8 + 4);
-                        const float2v w2[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
+                        const u32x4 w0 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8) * 4), w1 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8 + 4) * 4);
+                        const float2v w2[4] = {{__uint_as_float(w0[0]), __uint_as_float(w0[1])}, {__uint_as_float(w0[2]), __uint_as_float(w0[3])},
+                                               {__uint_as_float(w1[0]), __uint_as_float(w1[1])}, {__uint_as_float(w1[2]), __uint_as_float(w1[3])}};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
@@ -409,7 +416,12 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                         }
                     }
                     const float d[8] = {d2[0].x, d2[0].y, d2[1].x, d2[1].y, d2[2].x, d2[2].y, d2[3].x, d2[3].y};
-                    const float *scd = PAR + 9 * 32 + q * 8, *bsd = PAR + 10 * 32 + q * 8;
+                    const u32x4 s0_ = *reinterpret_cast<const u32x4 *>(PARB_ + (9 * 32 + q * 8) * 4), s1_ = *reinterpret_cast<const u32x4 *>(PARB_ + (9 * 32 + q * 8 + 4) * 4);
+                    const u32x4 b0_ = *reinterpret_cast<const u32x4 *>(PARB_ + (10 * 32 + q * 8) * 4), b1_ = *reinterpret_cast<const u32x4 *>(PARB_ + (10 * 32 + q * 8 + 4) * 4);
+                    const float scd[8] = {__uint_as_float(s0_[0]), __uint_as_float(s0_[1]), __uint_as_float(s0_[2]), __uint_as_float(s0_[3]),
+                                          __uint_as_float(s1_[0]), __uint_as_float(s1_[1]), __uint_as_float(s1_[2]), __uint_as_float(s1_[3])};
+                    const float bsd[8] = {__uint_as_float(b0_[0]), __uint_as_float(b0_[1]), __uint_as_float(b0_[2]), __uint_as_float(b0_[3]),
+                                          __uint_as_float(b1_[0]), __uint_as_float(b1_[1]), __uint_as_float(b1_[2]), __uint_as_float(b1_[3])};
                     float vd[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) vd[j] = x_actf(__builtin_fmaf(d[j] * up, scd[j], bsd[j]), a.dw_slope, a.dw_cap) * dmid;
