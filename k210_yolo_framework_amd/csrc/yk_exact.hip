@@ -1574,7 +1574,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 l.ns = nsteps >= 8 ? 3 : 2;                              // measured: 2 stages win up to K = 192, 3 from 384 on
                 if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 long sk = 1;
-                if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(8, (640 + tiles - 1) / tiles), nsteps / 8);
+                if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(7, (900 + tiles - 1) / tiles), nsteps / 8);   // measured (tools/xsweep.py): 7 slices at 105 tiles (8: +25 %), 4 at 280 (3: +9 %)
                 if (!yk_env_flag("YK_SPLITK", true)) sk = 1;
                 if (const char *e = yk_dev_env("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nsteps));
                 g.splitk = (int)std::max<long>(1, sk);

@@ -29,17 +29,19 @@ os.environ['YK_X_NOFUSE'] = '1'
 names0, ms0 = run()
 del os.environ['YK_X_NOFUSE']
 dw0 = [i for i, n in enumerate(names0) if n.startswith('x:dw3x3')]
+tns = tuple(int(v) for v in os.environ.get('XBS_TN', '1,2,3,6').split(','))
+dbs = tuple(int(v) for v in os.environ.get('XBS_DB', '0,1').split(','))
 for li in range(first, last + 1):
     if li >= len(dw0):
         break
     unf = (ms0[dw0[li]] + ms0[dw0[li] + 1]) * 1e3
     rows = []
-    for tm, tn, tw, db in itertools.product((2, 3, 4, 5, 8), (1, 2, 3, 6), (4, 5, 8, 10, 16, 20), (0, 1)):
+    for tm, tn, tw, db in itertools.product((2, 3, 4, 5, 8), tns, (4, 5, 8, 10, 16, 20), dbs):
         if tm * tn > 24:
             continue
         os.environ.update(YK_XB_LAYER=str(li), YK_XB_TM=str(tm), YK_XB_TN=str(tn), YK_XB_TW=str(tw), YK_XB_DB=str(db), YK_XB_ALWAYS='1')
         names, ms = run()
-        blocks = [i for i, n in enumerate(names) if n.startswith('x:dw3x3')]
+        blocks = [i for i, n in enumerate(names) if 'dw3x3' in n]
         i = blocks[li]
         if '+conv1x1' in names[i] and f',{2 if db else 1}stage' in names[i]:
             rows.append((float(ms[i]) * 1e3, names[i], tm, tn, tw, db))
