@@ -498,6 +498,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             const int oy = oy0 + py, ox = ox0 + px;
             const bool mok = py < a.TH && oy < a.Ho && ox < a.Wo;
             const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+            // the row's pixel index (or -1) rides in the 16 pad bytes of its staging row: the copy-out below needs no division per vector
+            if (wid == 0 && fq == 0) *reinterpret_cast<int *>(Cs + (p - i0 * 16) * C::CPITCH + BN * 4) = mok ? (int)m : -1;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nl = (wid * TN + j) * 16 + nl4, n = n0 + nl;
@@ -526,21 +528,19 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             }
         }
         if (i0 == 0) { XB_STAMP(8) }
+        const bool last = i0 + IPP >= TM;                             // (compile-time: the loop is unrolled)
+        if (last) x_amax_lds(smax, 0, rmax);                          // the tile's max rides on the barrier the staging needs anyway
         __syncthreads();
+        if (last && tid == 0 && smax[0]) x_amax_global(a.amax_out + (size_t)b * XS, smax[0]);
         const int rows = (TM - i0 < IPP ? TM - i0 : IPP) * 16;
         for (int v = tid; v < rows * VPR; v += 256) {
-            const int pr = v / VPR, cv = v - pr * VPR, p = i0 * 16 + pr;
-            const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
-            const int oy = oy0 + py, ox = ox0 + px, g = (n0 >> 3) + (cv >> 1);
-            if (py < a.TH && oy < a.Ho && ox < a.Wo && g < a.outG)
-                *reinterpret_cast<u32x4 *>(a.out + ((((size_t)b * a.Ho + oy) * a.Wo + ox) * a.outG + g) * 32 + (cv & 1) * 16) =
-                    *reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16);
+            const int pr = v / VPR, cv = v - pr * VPR;
+            const int m = *reinterpret_cast<const int *>(Cs + pr * C::CPITCH + BN * 4), g = (n0 >> 3) + (cv >> 1);
+            if (m >= 0 && g < a.outG)
+                *reinterpret_cast<u32x4 *>(a.out + ((size_t)m * a.outG + g) * 32 + (cv & 1) * 16) = *reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16);
         }
     }
     XB_STAMP(9)
-    x_amax_lds(smax, 0, rmax);
-    __syncthreads();
-    if (tid == 0 && smax[0]) x_amax_global(a.amax_out + (size_t)b * XS, smax[0]);
     XB_STAMP(10)
 #undef XB_STAMP
 }
