@@ -1571,7 +1571,10 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                     tiles = ((Mmax + g_xc[cfg].bm - 1) / g_xc[cfg].bm) * ((co + g_xc[cfg].bn - 1) / g_xc[cfg].bn);
                 }
                 l.cfg = cfg;
-                l.ns = nsteps >= 8 ? 3 : 2;                              // measured: 2 stages win up to K = 192, 3 from 384 on
+                // ring depth: 3 stages from K = 416 on.  (One batch in flight, K = 384 is a tie between 2 and 3; with three batches in
+                // flight 2 stages are +3.5 % on the whole step (tools/sweep3.sh): 48 KB less LDS per workgroup lets another stream's
+                // kernel onto the CU.)
+                l.ns = nsteps >= (yk_dev_env("YK_X_NS3") ? atoi(yk_dev_env("YK_X_NS3")) : 13) ? 3 : 2;
                 if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 long sk = 1;
                 if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(7, (900 + tiles - 1) / tiles), nsteps / 8);   // measured (tools/xsweep.py): 7 slices at 105 tiles (8: +25 %), 4 at 280 (3: +9 %)
