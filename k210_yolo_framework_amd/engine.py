@@ -331,12 +331,13 @@ class Pipeline:
     submit() returns at once; the returned (dets, counts) tensors belong to that slot's stream until the slot is reused
     `depth` submits later, so consume them (or call `wait`) before that."""
 
-    def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None):
+    def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None,
+                 precision: str = 'f16x2'):
         import torch
         require_gpu()
         self.depth = max(1, int(depth))
         self.spec, self.max_batch = spec, int(max_batch)
-        self.plans = [Plan(spec, weights, max_batch=max_batch, device=device) for _ in range(self.depth)]
+        self.plans = [Plan(spec, weights, max_batch=max_batch, device=device, precision=precision) for _ in range(self.depth)]
         self.outs = [p.outputs() for p in self.plans]
         cur = torch.cuda.current_stream()
         self.streams = [torch.cuda.Stream() for _ in range(self.depth)]

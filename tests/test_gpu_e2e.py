@@ -260,7 +260,8 @@ def test_baseline_config3_tiny_yolo_416_end_to_end():
     plan.close()
 
 
-def test_pipeline_three_batches_in_flight_equal_one_at_a_time():
+@pytest.mark.parametrize('precision', ['f16x2', 'f16'])
+def test_pipeline_three_batches_in_flight_equal_one_at_a_time(precision):
     """engine.Pipeline: different batches interleaved on 3 streams give exactly the detections of the same batches run alone."""
     import torch
     from k210_yolo_framework_amd import engine, netspec as ns
@@ -270,7 +271,7 @@ def test_pipeline_three_batches_in_flight_equal_one_at_a_time():
     B, N = 16, 9
     g = torch.Generator(device='cuda').manual_seed(5)
     frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g) for _ in range(N)]
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, precision=precision)
     cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
     ref = []
     for f in frames:
@@ -278,7 +279,7 @@ def test_pipeline_three_batches_in_flight_equal_one_at_a_time():
         d, c = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)
         torch.cuda.synchronize()
         ref.append((d.cpu().numpy().copy(), c.cpu().numpy().copy()))
-    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=3)
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=3, precision=precision)
     for rounds in range(3):                                    # several passes: slots are reused
         got = [pipe.submit(f) for f in frames[:3]] if rounds == 0 else None
         res = []
