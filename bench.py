@@ -36,7 +36,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per stream in flight (k210_yolo_framework_amd/__init__.py), before any HIP call
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)

@@ -68,3 +68,16 @@ def test_no_gpu_means_loud_failure(dll):
     rl.anchor_number, rl.anchor, rl.threshold, rl.nms_value = 3, anc, 0.6, 0.3
     dll.region_layer_init.restype = C.c_int
     assert dll.region_layer_init(C.byref(rl), 10, 7, 75, 320, 224) == -5
+
+
+def test_package_import_asks_for_one_hardware_queue_per_pipeline_stream():
+    """engine.Pipeline keeps three batches in flight on three HIP streams; the ROCm default of 4 hardware queues per process (shared with
+    the null stream and torch's pooled streams) can put two of them on one queue.  The package asks for 8 unless the user chose."""
+    import subprocess
+    import sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import k210_yolo_framework_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=str(ROOT))
+    assert out.stdout.strip() == '8', out.stderr
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import k210_yolo_framework_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=str(ROOT))
+    assert out.stdout.strip() == '2', out.stderr
