@@ -7,7 +7,8 @@ One "step" = one pass of the hot path over one batch of synthetic u8 frames ALRE
 `value` is quoted in the precision mode whose -m gpu test asserts BASELINE.json's tolerance (scores / coords within 1e-3 of the fp32
 path, identical detection sets): `--precision f16x2`, the default.  The plain fp16-storage mode (5e-3 worst case, tests/test_gpu_e2e.py)
 is measured in the same run and reported under `secondary`.
-`--streams` (default 3) independent batches are kept in flight (step i on stream i mod 3, own plan and decode scratch);
+`--streams` (default 4) independent batches are kept in flight (step i on stream i mod 4, own plan and decode scratch; measured
+with 8 hardware queues: 3 -> 75.4 k, 4 -> 77.4 k, 5 -> 65 k, 6 -> 70 k images/s);
 the one-batch-in-flight rate is measured in the same run and reported beside it.
 N>1: one process per GPU (torch.distributed / RCCL used only for the barrier + max-over-ranks of the
 timing); images are sharded across ranks, weights replicated, NO data-path collective ("weak" scaling).  `python bench.py --gpus N`
@@ -262,7 +263,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary measurements (variants, f16x2 mode, training step)')
-    ap.add_argument('--streams', type=int, default=3, help='independent batches in flight: step i runs on stream i %% S with its own plan, '
+    ap.add_argument('--streams', type=int, default=4, help='independent batches in flight: step i runs on stream i %% S with its own plan, '
                     'outputs and decode scratch (consecutive steps are independent batches)')
     ap.add_argument('--letterbox', action='store_true', help='SURVEY 8(d) variant (ii) as the timed step: 240x320 camera frames, letterboxed '
                     'on the GPU (yk_letterbox_u8) to the 224x320 network tensor')
