@@ -185,14 +185,29 @@ class Helper(object):
         print(INFO, 'data augment is ', str(is_training))
         rng = np.random.default_rng(rand_seed)
         rows = list(image_ann_list)
+        if not rows:
+            if repeat:                                     # the reference's infinite generator over an empty list never yields either;
+                raise ValueError('empty image list: nothing to batch')   # say so instead of spinning
+            return
+
+        def batch_of(picked):
+            samples = list(self.generator(is_training, is_resize, True, picked))
+            imgs = np.stack([im.astype(np.float32) for im, _ in samples])
+            labs = [np.stack([lab[l] for _, lab in samples]).astype(np.float32) for l in range(self.output_number)]
+            return imgs, labs
+        if repeat and len(rows) < batch_size:
+            # fewer rows than one batch (a small validation split): the reference repeats BEFORE it batches (utils.py:438-441), so its
+            # batches run across passes; a per-pass loop would never complete one
+            pending: List = []
+            while True:
+                pending += [rows[i] for i in rng.permutation(len(rows))]
+                while len(pending) >= batch_size:
+                    yield batch_of(pending[:batch_size])
+                    pending = pending[batch_size:]
         while True:
             order = rng.permutation(len(rows)) if is_training or repeat else np.arange(len(rows))
             for s in range(0, len(order) - batch_size + 1, batch_size):
-                picked = [rows[i] for i in order[s:s + batch_size]]
-                samples = list(self.generator(is_training, is_resize, True, picked))
-                imgs = np.stack([im.astype(np.float32) for im, _ in samples])
-                labs = [np.stack([lab[l] for _, lab in samples]).astype(np.float32) for l in range(self.output_number)]
-                yield imgs, labs
+                yield batch_of([rows[i] for i in order[s:s + batch_size]])
             if not repeat:
                 return
 

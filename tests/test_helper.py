@@ -179,6 +179,14 @@ def test_set_dataset_and_generator():
     assert all(s == (4, 224, 320, 3) for s in seen)
     img, boxes = next(h.generator(False, True, False, rows[:1]))
     assert img.shape == (224, 320, 3) and boxes.shape == (1, 5) and rows[0][1][0, 3] == 0.3   # the annotation itself is not modified
+    # a validation split SMALLER than one batch (3 rows, batches of 4): the reference repeats before it batches (utils.py:438-441), so
+    # its batches run across passes; an empty list is an error, not a silent spin
+    xv, yv = h.get_iter(False)
+    assert xv.shape == (4, 224, 320, 3) and sum(float(y[..., 4].sum()) for y in yv) == 4.0
+    assert h.get_iter(False)[0].shape == (4, 224, 320, 3)
+    with pytest.raises(ValueError):
+        next(h._create_dataset([], 4, 6, False, True))
+    assert list(h._create_dataset([], 4, 6, False, True, repeat=False)) == []
 
 
 def test_center_corner_roundtrip():
