@@ -135,8 +135,10 @@ __global__ void __launch_bounds__(256) splitk_sum16_kernel(const float *__restri
     const int zl = threadIdx.x >> 4, il = threadIdx.x & 15;
     const size_t tot = (size_t)M * N, i = (size_t)blockIdx.x * 16 + il;
     float s = 0.f;
-    if (i < tot)
+    if (i < tot) {
+#pragma unroll 8
         for (int z = zl; z < splits; z += 16) s += ws[(size_t)z * tot + i];
+    }
     red[zl][il] = s;
     __syncthreads();
     if (zl == 0 && i < tot) {
@@ -166,7 +168,9 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
     if (tiles < 512 && nk >= 8) {             // small grids (weight gradients, late 7x10 / 14x20 layers): fill the 256 CUs with K slices
         s = (int)std::min<long>((1024 + tiles - 1) / tiles, nk / 4);
         if (s < 1) s = 1;
-        if (s > 64) s = 64;                    // the finishing pass walks the slabs serially
+        // up to 512 slices when the result is one or two tiles (the weight gradients of the 112x160 layers: a 96x16 result over
+        // K = 286 720 rows ran on 64 workgroups at 0.9 TB/s); 16 lanes per output fold the slabs in the finishing pass
+        if (s > 512) s = 512;
     }
     g.splitk = s;
     g.ws = nullptr;
@@ -398,17 +402,21 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
 // dw[t][c] = sum_{b,oy,ox} dy * x(tap t).  One thread = one channel x one output row: it slides a 3x3 register window along
 // ox, so each step loads 3*stride new inputs instead of 9.  block = CW channel lanes x (256/CW) row lanes; grid (row chunks,
 // channel groups); partial[chunk][9][C] is folded by colsum_finish_kernel.
+// A thread sweeps ONE segment of an image row of one channel (shift register over x).  `segs` segments per row: whole rows gave the
+// 112x160x32 layer 224 workgroups of serial 160-pixel sweeps (73 MB at 1 TB/s); four segments per row are 896 workgroups.
 __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
-                                                            float *__restrict__ partial, int rows_per_chunk, int cw_log2) {
+                                                            float *__restrict__ partial, int rows_per_chunk, int cw_log2, int segs, int wseg) {
     __shared__ float red[9][256];
     const int CW = 1 << cw_log2, RL = 256 >> cw_log2;
     const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_log2;
     const int c = blockIdx.y * CW + cl;
-    const int rows = q.B * q.Ho;
+    const int rows = q.B * q.Ho * segs;                            // virtual rows: (image row, segment)
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (c < q.C)
-        for (int r = r0 + rl; r < r1; r += RL) {
+        for (int vr = r0 + rl; vr < r1; vr += RL) {
+            const int r = vr / segs, sg = vr - r * segs;
+            const int oxa = sg * wseg, oxb = min(q.Wo, oxa + wseg);
             const int b = r / q.Ho, oy = r - b * q.Ho;
             const float *xr[3];
             bool rv[3];
@@ -421,7 +429,7 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const f
             const float *gr = dy + ((size_t)r * q.Wo) * q.C + c;
             float w[3][3];
             auto ld = [&](int ky, int ix) -> float { return (rv[ky] && (unsigned)ix < (unsigned)q.Wi) ? xr[ky][(size_t)ix * q.C] : 0.f; };
-            int ix0 = -q.pad_l;
+            int ix0 = oxa * q.stride - q.pad_l;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 w[ky][0] = 0.f;                       // filled by the first shift below
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const f
                 w[ky][2] = ld(ky, ix0 + 1);
             }
             if (q.stride == 1) {
-                for (int ox = 0; ox < q.Wo; ++ox) {
+                for (int ox = oxa; ox < oxb; ++ox) {
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         w[ky][0] = w[ky][1];
@@ -441,11 +449,11 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const f
                     for (int t = 0; t < 9; ++t) s[t] += g * w[t / 3][t % 3];
                 }
             } else {
-                for (int ox = 0; ox < q.Wo; ++ox) {
+                for (int ox = oxa; ox < oxb; ++ox) {
                     const int ix = ox * q.stride - q.pad_l;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
-                        w[ky][0] = (ox && q.stride == 2) ? w[ky][2] : ld(ky, ix);
+                        w[ky][0] = (ox > oxa && q.stride == 2) ? w[ky][2] : ld(ky, ix);
                         w[ky][1] = ld(ky, ix + 1);
                         w[ky][2] = ld(ky, ix + 2);
                     }
@@ -499,13 +507,19 @@ extern "C" int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, i
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    const int cwl = lane_split(C), RL = 256 >> cwl, rows = B * Ho;
-    int rpc = ((rows + 511) / 512 + RL - 1) / RL * RL;          // whole row-lane rounds per chunk, at most ~512 chunks
+    const int cwl = lane_split(C), RL = 256 >> cwl, groups = (C + (1 << cwl) - 1) >> cwl;
+    // segments per image row: enough (row, segment) units for ~1024 workgroups of RL units each, at least 8 pixels per segment
+    int segs = (1024 * RL + B * Ho * groups - 1) / (B * Ho * groups);
+    segs = std::max(1, std::min(segs, std::min(8, Wo / 8)));
+    const int wseg = (Wo + segs - 1) / segs;
+    segs = (Wo + wseg - 1) / wseg;
+    const int rows = B * Ho * segs;
+    int rpc = ((rows + 2047) / 2048 + RL - 1) / RL * RL;        // whole row-lane rounds per chunk, at most ~2048 chunks
     const int chunks = (rows + rpc - 1) / rpc;
     float *partial = (float *)yk_scratch(dev, stream, 12, sizeof(float) * (size_t)chunks * 9 * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, q, x, dy, partial, rpc, cwl);
+    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, groups), dim3(256), 0, st, q, x, dy, partial, rpc, cwl, segs, wseg);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((9 * C + 3) / 4), dim3(256), 0, st, partial, chunks, 9 * C, dw, 1.f);
     YK_HIP(hipGetLastError());
     return YK_OK;
