@@ -279,10 +279,33 @@ __global__ void __launch_bounds__(256) col2im3x3_kernel(conv_geom q, const float
     dx[i] = s;
 }
 
+// four channels per thread, 32-bit index arithmetic: the element-wise kernel above spends its time in 64-bit divisions (the 14x20x704
+// head conv's 113 MB column matrix took 100 us, 1.1 TB/s)
+__global__ void __launch_bounds__(256) im2col3x3_v4_kernel(conv_geom q, const float *__restrict__ x, float *__restrict__ col, uint32_t total4) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const uint32_t C4 = (uint32_t)q.C >> 2;
+    const uint32_t r = i / C4, c4 = i - r * C4;
+    const uint32_t m = r / 9u, t = r - m * 9u;
+    const uint32_t my = m / (uint32_t)q.Wo, ox = m - my * (uint32_t)q.Wo;
+    const uint32_t b = my / (uint32_t)q.Ho, oy = my - b * (uint32_t)q.Ho;
+    const uint32_t ky = t / 3u, kx = t - ky * 3u;
+    const int iy = (int)oy * q.stride - q.pad_t + (int)ky, ix = (int)ox * q.stride - q.pad_l + (int)kx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)q.Hi && (unsigned)ix < (unsigned)q.Wi)
+        v = *reinterpret_cast<const float4 *>(x + (((size_t)b * q.Hi + iy) * q.Wi + ix) * q.C + c4 * 4);
+    *reinterpret_cast<float4 *>(col + (size_t)i * 4) = v;
+}
 extern "C" int yk_im2col3x3_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
                                 float *col, void *stream) {
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     const size_t total = (size_t)B * Ho * Wo * 9 * C;
+    if (C % 4 == 0 && total / 4 < 0xffffff00ull && (((uintptr_t)x | (uintptr_t)col) & 15) == 0) {
+        const uint32_t total4 = (uint32_t)(total / 4);
+        hipLaunchKernelGGL(im2col3x3_v4_kernel, dim3((total4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, x, col, total4);
+        YK_HIP(hipGetLastError());
+        return YK_OK;
+    }
     hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, x, col);
     YK_HIP(hipGetLastError());
     return YK_OK;
