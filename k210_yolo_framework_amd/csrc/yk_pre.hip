@@ -66,7 +66,27 @@ __global__ void __launch_bounds__(1024) u8_image_max_kernel(const uint8_t *__res
     __shared__ unsigned part[16];
     const uint8_t *p = f + (size_t)blockIdx.x * per_image;
     unsigned m = 0;
-    for (size_t i = threadIdx.x; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
+    size_t done = 0;
+    if ((((uintptr_t)p) & 15) == 0) {                              // 16 bytes per load (byte loads: 210 dependent-latency loads per thread, 28 us)
+        const size_t nv = per_image / 16;
+        const uint4 *v = reinterpret_cast<const uint4 *>(p);
+        unsigned a = 0;                                           // byte-wise max of the four lanes of a dword, folded at the end
+        for (size_t i = threadIdx.x; i < nv; i += 1024) {
+            const uint4 q = v[i];
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // per-byte max of a and w[k]: compare byte lanes separately (no carries between them)
+                const unsigned lo_a = a & 0x00ff00ffu, lo_w = w[k] & 0x00ff00ffu, hi_a = (a >> 8) & 0x00ff00ffu, hi_w = (w[k] >> 8) & 0x00ff00ffu;
+                const unsigned lo = max(lo_a & 0xffffu, lo_w & 0xffffu) | (max(lo_a >> 16, lo_w >> 16) << 16);
+                const unsigned hi = max(hi_a & 0xffffu, hi_w & 0xffffu) | (max(hi_a >> 16, hi_w >> 16) << 16);
+                a = lo | (hi << 8);
+            }
+        }
+        m = max(max(a & 255u, (a >> 8) & 255u), max((a >> 16) & 255u, a >> 24));
+        done = nv * 16;
+    }
+    for (size_t i = done + threadIdx.x; i < per_image; i += 1024) m = max(m, (unsigned)p[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
