@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const bool wave_live = n0 + wid * TN * 16 < a.N;                  // wave-uniform
     const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) * 16);
     const int nk = (a.dbg & 1) ? 0 : a.nk;
     for (int ks = 0; ks < nk; ++ks) {
@@ -439,8 +440,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(5) }
         if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
-        // ---- pointwise: three products per tile
-        if (!(a.dbg & 16)) {
+        // ---- pointwise: three products per tile (a wave whose 16*TN channels all lie past N - the last quarter of a 48- or 96-channel
+        // layer in a 64- / 128-wide tile - has nothing to multiply nor, below, to stage)
+        if (wave_live && !(a.dbg & 16)) {
             half8 xh[TM], xl[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -493,6 +495,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         if (i0 > 0) __syncthreads();                                  // the previous pass has been copied out
 #pragma unroll
         for (int i = i0; i < i0 + IPP && i < TM; ++i) {
+            if (!wave_live && wid != 0) break;                        // (wave 0 also writes the rows' pixel indices)
             const int p = i * 16 + fr;
             const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
             const int oy = oy0 + py, ox = ox0 + px;
