@@ -4,20 +4,23 @@
 // A workgroup (4 waves) owns a TH x TW patch of output pixels of ONE image (BM = 16*TM >= TH*TW GEMM rows) and BN = 64*TN output
 // channels (wave w: channels [w*16*TN, (w+1)*16*TN) of all BM pixels).  The channel axis is walked in steps of 32 (four groups of 8):
 //
-//   DMA(k)    one burst of `buffer_load ... lds` into stage k % 2: the input patch of the step's four channel groups
-//             ((TH-1)s+3 x (TW-1)s+3 positions x 4 groups, hi and lo halves in separate regions; pixels outside the image and groups
-//             past the tensor's last one get an out-of-range offset and arrive as zeros), the step's slice of the depthwise
-//             parameter table (nine taps, scale, bias x 32 channels fp32) and the pointwise weight tile [BN][32] (hi | lo, host order)
-//   dw(k)     one thread = one (pixel, channel group): nine taps from LDS, fp32 FMA chain, BN + activation, scaled by the MIDDLE
-//             exponent and split into (hi, lo) straight into the MFMA A tile - the depthwise tensor never exists in HBM
+//   DMA(k)    one burst of `buffer_load ... lds`: the input patch of the step's four channel groups ((TH-1)s+3 x (TW-1)s+3 positions
+//             x 4 groups, hi and lo halves in separate regions; pixels outside the image and groups past the tensor's last one get an
+//             out-of-range offset and arrive as zeros), the step's slice of the depthwise parameter table (nine taps, scale, bias x
+//             32 channels fp32) and the pointwise weight tile [BN][32] (hi | lo, host order)
+//   dw(k)     one thread = one (pixel, channel group): nine taps from LDS; hi + lo back in fp32 by one mixed-precision op per channel,
+//             packed fp32 FMAs on channel pairs, BN + activation, scaled by the MIDDLE exponent and split pair-wise into (hi, lo)
+//             straight into the MFMA A tile - the depthwise tensor never exists in HBM
 //   mma(k)    A x B on v_mfma_f32_16x16x32_f16, three products per tile
 //
 // Single-buffered and phase-shifted (two s_barriers per step): the patch of step k+1 is requested when dw(k) is over and lands under
 // mma(k); the weight tile of step k is requested when mma(k-1) is over and lands under dw(k).  One stage of everything keeps the
-// workgroup at ~70 KB for 384 output channels, so two workgroups share a CU and each one's depthwise (VALU) phase runs under the
-// other's MFMA phase.  The output tile leaves through LDS in passes of IPP row blocks (a whole 64 x 384 tile would need 99 KB).  The depthwise tensor's maximum is never measured, so
-// its exponent comes from its bound (gain_dw * amax(in) + off_dw) and the pointwise bound is built on that bound; the two levels of
-// over-estimate (2^3 x 2^7 in these networks) stay far inside fp16's exponent range (see the header of yk_exact.hip).
+// workgroup at <= 53 KB (tiles of 64 pixels x <= 192 channels or 128 pixels x 64 channels: xb_geometry), so THREE workgroups share a CU
+// and their DMA, depthwise (VALU) and MFMA phases overlap; the launches are bound by VALU issue (profiles/r03_x2_step_pmc.json).  The
+// output tile leaves through LDS in passes of IPP row blocks.  The depthwise tensor's maximum is never measured, so its exponent comes
+// from its bound (gain_dw * amax(in) + off_dw) and the pointwise bound is built on that bound; the two levels of over-estimate
+// (2^3 x 2^7 in these networks) stay far inside fp16's exponent range (see the header of yk_exact.hip).  STEM: the depthwise input is
+// the network's first conv, computed in the kernel from the frame window (xb_stem_patch).
 #pragma once
 
 struct xb_args {
