@@ -124,18 +124,20 @@ int yk_device_count(void);
 
 /* kpu_load_kmodel analogue.  ops: [n_ops][YK_OP_FIELDS] int32; tensors: [n_tensors][4]
  * int32 (h, w, c, is_input); blob: fp32 weights/scale/bias addressed by the op rows.
- * The plan owns every device buffer (weights in fp16, activation arena sized for
- * max_batch).  Arithmetic: fp16 storage, fp32 accumulation, fp32 network outputs. */
+ * The plan owns every device buffer (weights, activation arena sized for max_batch).
+ * Arithmetic: YK_PRECISION_F16X2 below - the mode whose outputs stay within 1e-3 of the fp32 Keras path with identical
+ * class / box indices (what `yolo_model.predict`, keras_inference.py:88, returns); fp32 network outputs. */
 int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
                    const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
                    int device);
 /* The same with a choice of arithmetic (there is no reference counterpart: Keras computes in fp32 on the CPU):
- *   YK_PRECISION_F16    fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulate — the throughput mode
- *                       (= yk_plan_create).  Scores drift ~2e-4 mean / ~2e-3 max from the fp32 Keras path.
- *   YK_PRECISION_F16X2  fp32 activations in HBM, compensated fp16 MFMA operands (x = hi + lo, three MFMAs per product),
- *                       fp32 accumulate: fp32-class results (the "within 1e-3, indices exact" clause of the north star;
- *                       measured 2e-6 of max|logit|), about 2.7x the time of the fp16 plan.  Per-image operand scaling:
- *                       results never depend on the batch mates. */
+ *   YK_PRECISION_F16X2  (= yk_plan_create) activations in HBM as fp16 PAIRS, x * 2^-e = hi + lo (22 significant bits, the bytes of
+ *                       fp32, per-image storage exponent e), weights split the same way once; three fp16 MFMAs per product
+ *                       (w_lo*x_hi + w_hi*x_lo + w_hi*x_hi), fp32 accumulate: fp32-class results (the "within 1e-3, indices
+ *                       exact" clause of the north star; measured 2e-6 of max|logit|).  Per-image operand scaling: results
+ *                       never depend on the batch mates.
+ *   YK_PRECISION_F16    fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulate: about twice as fast, and outside
+ *                       the tolerance (scores drift ~2e-4 mean / 2e-3..5e-3 max from the fp32 Keras path). */
 #define YK_PRECISION_F16 0
 #define YK_PRECISION_F16X2 1
 int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,

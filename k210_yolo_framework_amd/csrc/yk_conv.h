@@ -110,7 +110,8 @@ struct first_args {
     yk_half *out;
 };
 int yk_launch_first(const first_args &a, hipStream_t st);
-int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st);
+int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st, uint32_t *zero = nullptr,
+                     size_t zero_words = 0);
 
 // ---- depthwise 3x3 ------------------------------------------------------------------------------
 struct dw_args {

@@ -1064,10 +1064,16 @@ int yk_launch_first(const first_args &a, hipStream_t st) {
 
 // per-image max of u8 frames: YK_MAXP workgroups per image write partial maxima img_max[b*YK_MAXP + j]
 // (plain stores, no atomics, no memset); the stem conv folds the partials when it builds its LUT.
+// `zero` (may be null): a word array this first launch of a step also clears - the f16x2 plan's per-image running maxima, which every
+// later launch of the step accumulates into (a separate hipMemsetAsync was a 4 us fill launch per step).
 __global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__ f, size_t per_image, int vec_ok,
-                                                     unsigned *__restrict__ img_max) {
+                                                     unsigned *__restrict__ img_max, uint32_t *__restrict__ zero, size_t zero_words) {
     __shared__ unsigned part[4];
     const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+    if (zero) {
+        const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)b * gridDim.x + j) * 256 + tid; i < zero_words; i += nthr) zero[i] = 0u;
+    }
     const uint8_t *p = f + (size_t)b * per_image;
     unsigned m = 0;
     const size_t t = (size_t)j * 256 + tid, nth = (size_t)gridDim.x * 256;
@@ -1103,10 +1109,10 @@ __global__ void __launch_bounds__(256) u8_max_kernel(const uint8_t *__restrict__
     if (tid == 0) img_max[b * YK_MAXP + j] = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
-int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st) {
+int yk_launch_u8_max(const uint8_t *frames, size_t per_image, int batch, unsigned *img_max, hipStream_t st, uint32_t *zero, size_t zero_words) {
     const int vec_ok = (per_image % 16 == 0) && ((uintptr_t)frames % 16 == 0);
     static const int parts = yk_dev_env("YK_MAXP_RT") ? std::max(1, std::min(YK_MAXP, atoi(yk_dev_env("YK_MAXP_RT")))) : YK_MAXP;   // unused slots stay 0
-    hipLaunchKernelGGL(u8_max_kernel, dim3(parts, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max);
+    hipLaunchKernelGGL(u8_max_kernel, dim3(parts, batch), dim3(256), 0, st, frames, per_image, vec_ok, img_max, zero, zero_words);
     return YK_OK;
 }
 

@@ -141,7 +141,7 @@ extern "C" void yk_plan_destroy(yk_plan_t *p) {
 extern "C" int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
                               const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
                               int device) {
-    return yk_plan_create_ex(out, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch, device, YK_PRECISION_F16);
+    return yk_plan_create_ex(out, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch, device, YK_PRECISION_F16X2);
 }
 
 extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,

@@ -40,6 +40,12 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define X_OOB 0x40000000u       // an offset no tensor reaches (tensors are < 1 GiB): buffer loads past num_records return zeros
+// phase knock-out bits of the developer builds (tools/xbench.py, `make DEV=1`); a constant false in the shipped kernels
+#ifdef YK_DEV
+#define X_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define X_DBG(a, bit) false
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
 
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     // K range of this split: steps [kt0, kt0 + nk) of the walk  seg 0: tap-major over s0   |   seg 1: tap-major over s1
     const int kb = a.taps * a.nc0, nk_all = kb + a.taps * a.nc1;
     const int per = (nk_all + a.splitk - 1) / a.splitk;
-    const int kt0 = vz * per, nk = (a.dbg & 1) ? 0 : max(0, min(per, nk_all - kt0));
+    const int kt0 = vz * per, nk = X_DBG(a, 1) ? 0 : max(0, min(per, nk_all - kt0));
     const int lim = kt0 + nk;
 
     // ---- this lane's A rows (fixed over the walk): row l>>2 of the 16-row blocks wid*AR + it, fetching chunk (l&3) ^ ((row>>1)&3)
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) dma(s);                       // steps past `lim` deposit zeros and keep the vmcnt arithmetic uniform
-    if (!(a.dbg & 2)) xg_prep<BM, NW>(a, b0, bl, s_up, s_resc, s_down, s_rup, s_amax);   // slot loads fly with the prologue DMAs
+    if (!X_DBG(a, 2)) xg_prep<BM, NW>(a, b0, bl, s_up, s_resc, s_down, s_rup, s_amax);   // slot loads fly with the prologue DMAs
     bool in0 = a.nc1 > 0 && kt0 < kb;                               // accumulators still in src0's units
     auto rescale = [&]() {
 #pragma unroll
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
             in0 = false;
         }
         dma(wr);
-        if (!(a.dbg & 16)) compute(rd);
+        if (!X_DBG(a, 16)) compute(rd);
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
@@ -503,7 +509,7 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) mine[(i * TN + j) * C::NT] = acc[i][j];
     } else {
-        if (!(a.dbg & 4)) xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, sc, bs, s_up, s_down, s_rup, s_amax);
+        if (!X_DBG(a, 4)) xg_epilogue<BM, BN, WM, WN>(a, acc, m0, n0, b0, bl, rowb, sc, bs, s_up, s_down, s_rup, s_amax);
     }
 }
 
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
         const uint32_t img = (uint32_t)a.in.H * a.in.W * G * 32u;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in.p + (size_t)b * img), 0, img, 0x00020000);
         const int nwf = a.NT >> 6;
-        if (wid < nwf && !(a.dbg & 1))
+        if (wid < nwf && !X_DBG(a, 1))
             for (int q0 = wid * 64; q0 < a.n16p; q0 += nwf * 64) {
                 const uint32_t q = q0 + lane;
                 const uint32_t pos = x_div(q, a.fd_gs), g = q - pos * a.GS;
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
     const float sc[8] = {sc0.x * up, sc0.y * up, sc0.z * up, sc0.w * up, sc1.x * up, sc1.y * up, sc1.z * up, sc1.w * up};
     const float bs[8] = {bs0.x, bs0.y, bs0.z, bs0.w, bs1.x, bs1.y, bs1.z, bs1.w};
     float mx = 0.f;
-    if (tid < a.NT && !(a.dbg & 2))
+    if (tid < a.NT && !X_DBG(a, 2))
         for (int p = p0; p < a.TH * a.TW; p += PP) {
             const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
             const int oy = oy0 + py, ox = ox0 + px;
@@ -658,7 +664,7 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
             }
             x_split8(vd, hi, lo);
             uint8_t *o = a.out + ((((size_t)b * a.Ho + oy) * a.Wo + ox) * G + g0 + gl) * 32;
-            if (a.dbg & 4) continue;
+            if (X_DBG(a, 4)) continue;
             *reinterpret_cast<half8 *>(o) = hi;
             *reinterpret_cast<half8 *>(o + 16) = lo;
         }
@@ -1701,16 +1707,24 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     return YK_OK;
 }
 
+// clears the running maxima when the step has no u8_max launch to do it (fp32 frames)
+__global__ void __launch_bounds__(256) xzero_kernel(uint32_t *__restrict__ z, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) z[i] = 0u;
+}
+
 int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream_t st, hipEvent_t *ev) {
-    YK_HIP(hipMemsetAsync(p->d_amax, 0, sizeof(uint32_t) * p->T.size() * p->max_batch * XS, st));
+    // the per-image running maxima are cleared by the step's first launch (no fill launch, nothing but kernels in a captured step)
+    const size_t amax_words = p->T.size() * (size_t)p->max_batch * XS;
     int li = 0;
     for (xlaunch &l : p->L) {
         if (ev) YK_HIP(hipEventRecord(ev[2 * li], st));
         switch (l.kind) {
         case XK_U8MAX:
             if (!in_f32) {
-                int rc = yk_launch_u8_max((const uint8_t *)d_in, (size_t)p->in_h * p->in_w * 3, batch, p->d_imgmax, st);
+                int rc = yk_launch_u8_max((const uint8_t *)d_in, (size_t)p->in_h * p->in_w * 3, batch, p->d_imgmax, st, p->d_amax, amax_words);
                 if (rc) return rc;
+            } else {
+                hipLaunchKernelGGL(xzero_kernel, dim3(128), dim3(256), 0, st, p->d_amax, amax_words);
             }
             break;
         case XK_STEM: {

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     // Workgroups walk the channel steps from different starting points (a function of the tile's place in ITS image only, so an
     // image's arithmetic does not depend on the batch): 256 CUs asking one L2 for the same weight tile in the same microsecond
     // serialise on its banks
-    const int rot = (a.nk == 1 || (a.dbg & 32)) ? 0 : (int)(tl - x_div(tl, a.fd_nk) * (uint32_t)a.nk);
+    const int rot = (a.nk == 1 || X_DBG(a, 32)) ? 0 : (int)(tl - x_div(tl, a.fd_nk) * (uint32_t)a.nk);
     auto kstep = [&](int i) {
         const int k = i + rot;
         return k >= a.nk ? k - a.nk : k;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             }
         }
     };
-    if (!(a.dbg & 1)) {
+    if (!X_DBG(a, 1)) {
         dma_patch(0);
         if (a.db) dma_b(0);
     }
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     const bool wave_live = n0 + wid * TN * 16 < a.N;                  // wave-uniform
     const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) * 16);
-    const int nk = (a.dbg & 1) ? 0 : a.nk;
+    const int nk = X_DBG(a, 1) ? 0 : a.nk;
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of patch(ks) have landed
         __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         const unsigned char *PARB_ = HI + a.n16p * 32;
         const float up = sf[0], dmid = sf[1];
         // ---- depthwise: item = (pixel p, group q of this step)
-        if (!(a.dbg & 2))
+        if (!X_DBG(a, 2))
             for (int it = tid; it < BM * 4; it += 256) {
                 const int p = it >> 2, q = it & 3;
                 const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile (a wave whose 16*TN channels all lie past N - the last quarter of a 48- or 96-channel
         // layer in a 64- / 128-wide tile - has nothing to multiply nor, below, to stage)
-        if (wave_live && !(a.dbg & 16)) {
+        if (wave_live && !X_DBG(a, 16)) {
             half8 xh[TM], xl[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     __builtin_amdgcn_s_barrier();                                     // LDS becomes the output tile
     asm volatile("" ::: "memory");
     XB_STAMP(7)
-    if (a.dbg & 4) return;
+    if (X_DBG(a, 4)) return;
     // ---- epilogue: lane holds channels n..n+3 of pixel i*16 + fr; the tile leaves through LDS in passes of IPP row blocks
     unsigned char *Cs = xsm;
     const float umid = sf[2], dout = sf[3], rup = sf[4];

@@ -116,9 +116,10 @@ class _DevView:
 class Plan:
     """kpu_load_kmodel analogue (main.c:274): a compiled, device-resident network."""
 
-    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None, precision: str = 'f16'):
-        """precision: 'f16' (fp16 activations, the throughput mode) or 'f16x2' (fp32 activations, compensated fp16 MFMA
-        operands: fp32-class results, see include/yolo_hip.h YK_PRECISION_*)."""
+    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None, precision: str = 'f16x2'):
+        """precision: 'f16x2' (default; activations stored as fp16 pairs hi + lo, compensated fp16 MFMA operands: the mode that meets
+        BASELINE.json's 1e-3 / exact-index tolerance) or 'f16' (fp16 activations, about twice as fast, 5e-3 worst case on the
+        scores); see include/yolo_hip.h YK_PRECISION_*."""
         import torch
         require_gpu()
         if precision not in PRECISIONS:

@@ -163,7 +163,7 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
 
 
 def validate(tr, h: Helper, spec, batch: int, rank: int) -> float:
-    """validation_data pass (keras_train.py:96-98): inference-mode forward on the fp16 engine + the same loss."""
+    """validation_data pass (keras_train.py:96-98): inference-mode forward on the engine (the f16x2 mode, the boundary default) + the same loss."""
     import torch
     tot, n = 0.0, 0
     e = 5 + spec.class_num

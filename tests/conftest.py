@@ -22,9 +22,14 @@ def _gpu_present() -> bool:
         return False
 
 
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly, not skip silently; `-m "not gpu"` never imports HIP.
-    pass
+@pytest.fixture(autouse=True)
+def _gpu_tests_fail_loudly_without_a_gpu(request):
+    """`-m gpu` on a box without a GPU must FAIL, never skip or pass on some fallback: every gpu-marked test first asks the
+    product for its device (engine.require_gpu raises YkError when the library or the device is missing)."""
+    if request.node.get_closest_marker('gpu') is not None:
+        from k210_yolo_framework_amd import engine
+        engine.require_gpu()
+    yield
 
 
 @pytest.fixture(scope='session')

@@ -14,7 +14,7 @@ spec = ns.NETWORKS[name]((224, 320, 3), 3, 20, alpha=alpha)
 w = spec.init_weights(seed=1)
 B = 4
 frames = np.random.default_rng(0).integers(0, 256, (B, 224, 320, 3), dtype=np.uint8)
-plan = engine.Plan(spec, w, max_batch=B)
+plan = engine.Plan(spec, w, max_batch=B, precision='f16')
 plan.run_u8(torch.from_numpy(frames).cuda())
 torch.cuda.synchronize()
 x = oracle.normalise_u8(frames)

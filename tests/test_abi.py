@@ -70,6 +70,53 @@ def test_no_gpu_means_loud_failure(dll):
     assert dll.region_layer_init(C.byref(rl), 10, 7, 75, 320, 224) == -5
 
 
+def test_boundary_default_is_the_conforming_mode():
+    """A caller that follows INTEGRATION.md section 2 (yk_plan_create / engine.Plan / the plugin classes with no precision argument)
+    gets the mode whose results meet BASELINE.json's tolerance (f16x2); the faster fp16-storage mode is opt-in."""
+    import inspect
+    from k210_yolo_framework_amd import engine, yolonet
+    assert inspect.signature(engine.Plan.__init__).parameters['precision'].default == 'f16x2'
+    assert inspect.signature(engine.Pipeline.__init__).parameters['precision'].default == 'f16x2'
+    assert yolonet.YoloModel(None, {}, False).precision == 'f16x2'
+    src = (ROOT / 'k210_yolo_framework_amd' / 'csrc' / 'yk_engine.hip').read_text()
+    body = src[src.index('extern "C" int yk_plan_create('):src.index('extern "C" int yk_plan_create_ex(')]
+    assert 'YK_PRECISION_F16X2' in body and 'YK_PRECISION_F16)' not in body
+
+
+@pytest.mark.gpu
+def test_yk_plan_create_through_ctypes_gives_fp32_class_results(dll):
+    """The C entry point itself (not the Python default): outputs within 1e-4 of max|logit| of the FP32 oracle."""
+    import numpy as np
+    import torch
+    import oracle
+    from k210_yolo_framework_amd import netspec
+    spec = netspec.yolo_mobilev1((64, 96, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=2)
+    ops, tens, blob = spec.compile_plan(w)
+    ops, tens = np.ascontiguousarray(ops, np.int32), np.ascontiguousarray(tens, np.int32)
+    blob, outs = np.ascontiguousarray(blob, np.float32), np.ascontiguousarray(spec.outputs, np.int32)
+    h = C.c_void_p()
+    vp = C.c_void_p
+    dll.yk_last_error.restype = C.c_char_p
+    rc = dll.yk_plan_create(C.byref(h), ops.ctypes.data_as(vp), C.c_int(len(ops)), tens.ctypes.data_as(vp), C.c_int(len(tens)),
+                            blob.ctypes.data_as(vp), C.c_size_t(blob.size), outs.ctypes.data_as(vp), C.c_int(len(outs)), C.c_int(2), C.c_int(0))
+    assert rc == 0, dll.yk_last_error()
+    frames = np.random.default_rng(1).integers(0, 256, (2, 64, 96, 3), dtype=np.uint8)
+    fd = torch.from_numpy(frames).cuda()
+    assert dll.yk_run_u8(h, vp(fd.data_ptr()), C.c_int(2), vp(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    ref = oracle.net_forward(spec.compile_plan(w), oracle.normalise_u8(frames), emulate_f16=False, out_ids=spec.outputs)
+    for i, r in enumerate(ref):
+        ptr, nb, hh, ww, cc = vp(), C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
+        assert dll.yk_get_output(h, C.c_int(i), C.byref(ptr), C.byref(nb), C.byref(hh), C.byref(ww), C.byref(cc)) == 0
+        got = np.empty((2, hh.value, ww.value, cc.value), np.float32)
+        from torch.cuda import cudart
+        assert int(cudart().cudaMemcpy(got.ctypes.data, ptr.value, got.nbytes, 2)) == 0           # cudaMemcpyDeviceToHost
+        assert np.abs(got - r.reshape(got.shape)).max() <= 1e-4 * np.abs(r).max()
+    dll.yk_plan_destroy.restype = None
+    dll.yk_plan_destroy(h)
+
+
 def test_package_import_asks_for_one_hardware_queue_per_pipeline_stream():
     """engine.Pipeline keeps three batches in flight on three HIP streams; the ROCm default of 4 hardware queues per process (shared with
     the null stream and torch's pooled streams) can put two of them on one queue.  The package asks for 8 unless the user chose."""

@@ -241,7 +241,7 @@ def test_baseline_config3_tiny_yolo_416_end_to_end():
     w = spec.init_weights(seed=1)
     B = 8
     frames = np.random.default_rng(3).integers(0, 256, (B, 416, 416, 3), dtype=np.uint8)
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, precision='f16')
     plan.run_u8(torch.from_numpy(frames).cuda())
     cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, (416, 416), spec.out_hw())
     dets, counts = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)

@@ -23,7 +23,7 @@ def _layerwise(spec, w, B, fuse=True, splitk=True, seed=0):
     os.environ['YK_FUSE_DWPW'] = '1' if fuse else '0'
     os.environ['YK_SPLITK'] = '1' if splitk else '0'
     frames = np.random.default_rng(seed).integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8)
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, precision='f16')
     plan.run_u8(torch.from_numpy(frames).cuda())
     torch.cuda.synchronize()
     gpu = {0: oracle.normalise_u8(frames)}

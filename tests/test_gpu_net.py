@@ -137,7 +137,7 @@ def test_batch_smaller_than_max_batch_and_rerun():
     spec = ns.yolo_mobilev1((64, 96, 3), 3, 20, alpha=0.75)
     w = spec.init_weights(seed=4)
     rng = np.random.default_rng(3)
-    plan = engine.Plan(spec, w, max_batch=8)
+    plan = engine.Plan(spec, w, max_batch=8, precision='f16')
     f1 = rng.integers(0, 256, (8, 64, 96, 3), dtype=np.uint8)
     plan.run_u8(torch.from_numpy(f1).cuda())
     torch.cuda.synchronize()

@@ -9,7 +9,7 @@ w = spec.init_weights(seed=1)
 cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
 for S in (1, 2, 4):
     B = 32 // S
-    plans = [engine.Plan(spec, w, max_batch=B) for _ in range(S)]
+    plans = [engine.Plan(spec, w, max_batch=B, precision='f16') for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda') for _ in range(S)]
     def step():

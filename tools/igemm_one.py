@@ -13,7 +13,7 @@ y = s.conv(x, C2, int(os.environ.get('KS', '3')), act=ns.LEAKY01, name='conv2d_3
 z = s.conv(y, 75, 1, bn=False, bias=True, name='conv2d_4', net_output=True)
 s.outputs = [z]
 w = s.init_weights(1)
-plan = engine.Plan(s, w, max_batch=B)
+plan = engine.Plan(s, w, max_batch=B, precision='f16')
 f = torch.rand(B, H, W, 3, device='cuda')
 for _ in range(int(os.environ.get('ITERS', '10'))):
     plan.run_f32(f)

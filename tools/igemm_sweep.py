@@ -14,7 +14,7 @@ for cfg in ['', '4', '0', '8', '9', '10', '5', '3']:
     for split in ['', '2', '4', '6', '8', '12', '16', '24']:
         os.environ['YK_IGEMM_FORCE'], os.environ['YK_SPLIT_FORCE'] = cfg, split
         try:
-            plan = engine.Plan(spec, w, max_batch=B)
+            plan = engine.Plan(spec, w, max_batch=B, precision='f16')
         except Exception as e:
             print(cfg, split, 'ERR', e)
             continue

@@ -14,7 +14,7 @@ spec = ns.NETWORKS[name]((*shape, 3), 3, 20, alpha=alpha)
 w = spec.init_weights(seed=1)
 cols = {}
 for B in batches:
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, precision='f16')
     frames = torch.randint(0, 256, (B, *shape, 3), dtype=torch.uint8, device='cuda')
     for _ in range(5):
         plan.run_u8(frames)

@@ -3,7 +3,7 @@ import numpy as np, torch
 from k210_yolo_framework_amd import engine, netspec as ns
 from k210_yolo_framework_amd.helper import VOC_ANCHORS
 spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
-plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=32)
+plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=32, precision='f16')
 frames = torch.randint(0, 256, (32, 224, 320, 3), dtype=torch.uint8, device='cuda')
 plan.run_u8(frames); torch.cuda.synchronize()
 outs = plan.outputs()

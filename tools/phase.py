@@ -9,7 +9,7 @@ from k210_yolo_framework_amd import engine, netspec as ns
 li = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
-plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=B)
+plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=B, precision='f16')
 frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda')
 for _ in range(3):
     plan.run_u8(frames)
