@@ -271,6 +271,7 @@ def main():
                     'detections are copied back (reported for reference; never the headline value)')
     ap.add_argument('--precision', choices=['f16', 'f16x2'], default='f16x2',
                     help="'f16x2' (default): the mode that meets BASELINE.json's 1e-3 / exact-set tolerance; 'f16': fp16 storage, 5e-3 worst case")
+    ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no hipGraph replay of the step)')
     ap.add_argument('--stub', action='store_true', help='no GPU: sleeping step over gloo (launcher / rendezvous self-test)')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
@@ -311,57 +312,38 @@ def main():
             torch.cuda.synchronize()
 
     class Harness:
-        """S batches in flight; one step = (optional H2D) -> (optional letterbox) -> yk_run_u8 -> yk_decode_py -> (optional D2H)."""
+        """S batches in flight through the product API (engine.Pipeline): one step = (optional H2D) -> (optional letterbox) -> yk_run_u8 ->
+        yk_decode_py -> (from host: detections written to pinned host memory at their live size).  graph=True: each slot's step is a
+        captured hipGraph, one host call per batch."""
 
-        def __init__(self, S, precision, letterbox=False, from_host=False):
+        def __init__(self, S, precision, letterbox=False, from_host=False, graph=True):
             self.S, self.letterbox, self.from_host = max(1, S), letterbox, from_host
-            self.plans = [engine.Plan(spec, weights, max_batch=B, device=local, precision=precision) for _ in range(self.S)]
-            self.outs = [p.outputs() for p in self.plans]
-            self.streams = [torch.cuda.Stream() for _ in range(self.S)]
-            for st in self.streams:
-                st.wait_stream(torch.cuda.current_stream())
-            self.tick = 0
+            self.pipe = engine.Pipeline(spec, weights, VOC_ANCHORS, max_batch=B, depth=self.S, device=local, precision=precision,
+                                        graph=graph, src_hw=(240, 320) if letterbox else None)
+            self.plans = self.pipe.plans
+            self.src = cam if letterbox else frames
+            self.host_s = 0.0
             if from_host:
-                src = cam if letterbox else frames
-                self.host = [torch.empty(src.shape, dtype=torch.uint8).pin_memory() for _ in range(self.S)]
-                for hbuf in self.host:
-                    hbuf.copy_(src)
-                self.copy_streams = [torch.cuda.Stream() for _ in range(self.S)]      # H2D on its own stream per slot: the copy engine
-                self.dev_in = [torch.empty_like(src) for _ in range(self.S)]          # overlaps the previous batch's kernels
-                self.h_dets = [torch.empty((B, 600, 6), dtype=torch.float32).pin_memory() for _ in range(self.S)]
-                self.h_cnt = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(self.S)]
+                h = self.src.cpu()
+                for i in range(self.S):
+                    self.pipe.host_input(i).copy_(h)              # the frames of every slot wait in pinned host memory
 
         def step(self):
-            i = self.tick % self.S
-            self.tick += 1
-            st = self.streams[i]
             if self.from_host:
-                cs = self.copy_streams[i]
-                cs.wait_stream(st)                                   # the slot's previous consumer has finished with dev_in[i]
-                with torch.cuda.stream(cs):
-                    self.dev_in[i].copy_(self.host[i], non_blocking=True)
-                st.wait_stream(cs)
-            with torch.cuda.stream(st):
-                x = self.dev_in[i] if self.from_host else (cam if self.letterbox else frames)
-                if self.letterbox:
-                    x = engine.letterbox_u8(x, (224, 320))
-                self.plans[i].run_u8(x)
-                dets, counts = engine.decode_py(cfg, self.outs[i], B, None, 0.7, 0.5)
-                if self.from_host:
-                    self.h_dets[i].copy_(dets, non_blocking=True)
-                    self.h_cnt[i].copy_(counts, non_blocking=True)
-            return dets, counts
+                return self.pipe.submit_host(None)
+            return self.pipe.submit(self.src, sync_input=False)   # resident frames: nothing to order them behind
 
         def measure(self, steps, warmup, min_s=MIN_REGION_S, max_regions=64):
             for _ in range(max(warmup, 3)):
                 self.step()
             sync_all()
-            times = []
+            times, host = [], []
             while True:
                 sync_all()
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     self.step()
+                t1 = time.perf_counter()
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
                 if dist is not None:
@@ -369,23 +351,48 @@ def main():
                     dist.barrier()
                     el = shard.max_over_ranks(el, dist, device='cuda')
                 times.append(el)
+                host.append((t1 - t0) / steps)
                 if sum(times) >= min_s or len(times) >= max_regions:
                     break
+            self.host_s = statistics.median(host)                 # host time to SUBMIT one step (the GPU runs behind it)
             return statistics.median(times), len(times)
 
         def close(self):
             torch.cuda.synchronize()
-            for p in self.plans:
-                p.close()
+            self.pipe.close()
 
     S = max(1, args.streams)
-    head = Harness(S, args.precision, letterbox=args.letterbox, from_host=args.from_host)
+    use_graph = not args.eager
+    head = Harness(S, args.precision, letterbox=args.letterbox, from_host=args.from_host, graph=use_graph)
     elapsed, regions = head.measure(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    single = Harness(1, args.precision, letterbox=args.letterbox, from_host=args.from_host)
+    host_us = head.host_s * 1e6
+    graph_nodes = max((g.nodes for sl in head.pipe.slots for g in sl.graphs.values()), default=0)
+    single = Harness(1, args.precision, letterbox=args.letterbox, from_host=args.from_host, graph=use_graph)
     el1, _ = single.measure(min(args.steps, 100), 5)
     single_ms = el1 / min(args.steps, 100) * 1e3
+    # SURVEY 8(d) "end to end" with the PCIe legs: the same step fed from pinned host memory (H2D inside the captured step), detections
+    # delivered to pinned host memory; every rank takes part (8(e): host feeding is where the N-GPU curve is expected to bend)
+    value_from_host, fh_host_us = None, None
+    if not args.from_host and not args.no_secondary:
+        ok, fh, err = 1, None, ''
+        try:
+            fh = Harness(S, args.precision, letterbox=args.letterbox, from_host=True, graph=use_graph)
+        except Exception as e:
+            ok, err = 0, f'{type(e).__name__}: {e}'
+        if dist is not None:                                         # agree before entering the timed region's barrier
+            t = torch.tensor([ok], device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            el_fh, _ = fh.measure(min(args.steps, 100), 10)
+            value_from_host = world * B * min(args.steps, 100) / el_fh
+            fh_host_us = fh.host_s * 1e6
+        elif rank == 0:
+            print(f'bench.py: from-host harness failed on some rank: {err}', file=sys.stderr)
+        if fh is not None:
+            fh.close()
 
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream.  Algorithmic bytes are SURVEY 8(d)'s (every layer's
@@ -446,8 +453,12 @@ def main():
         roof_step_us = alg_gb / HBM_PEAK_GBS * 1e6                            # the whole step is HBM-bound under this model
         inflight = f'{S} batches in flight' if S > 1 else 'one batch in flight'
         out = {
-            'metric': f'images/sec end-to-end, yolo_mobilev1-0.75 320x240 b32 ({inflight})',
-            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'metric': f'images/sec end-to-end, yolo_mobilev1-0.75 320x240 b32 ({inflight}; `value`: frames resident in HBM, '
+                      '`value_from_host`: frames from pinned host memory + detections back to the host, PCIe inside the step)',
+            'value': round(value, 1), 'value_from_host': None if value_from_host is None else round(value_from_host, 1),
+            'from_host_frac_of_value': None if value_from_host is None else round(value_from_host / value, 3),
+            'from_host_h2d_GBps': None if value_from_host is None else round(value_from_host / world * 224 * 320 * 3 / 1e9, 2),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16 storage / f32 accumulate' if args.precision == 'f16' else 'f16x2 (compensated fp16 MFMA operands: x = hi + lo, fp32 accumulate)',
             'data': 'synthetic u8 frames resident in HBM, seeded random-init weights',
@@ -456,7 +467,9 @@ def main():
                                    f'20-class VOC head, u8 normalise + backbone/head + python-mode decode + per-class NMS; {inflight} '
                                    '(independent batches on separate HIP streams, one plan each)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
-                       'launch_mode': 'eager', 'batches_in_flight': S, 'precision': args.precision,
+                       'launch_mode': 'graph' if use_graph else 'eager', 'graph_nodes_per_step': graph_nodes,
+                       'host_us_per_step': round(host_us, 1),
+                       'from_host_host_us_per_step': None if fh_host_us is None else round(fh_host_us, 1), 'batches_in_flight': S, 'precision': args.precision,
                        'tolerance_carried': ('BASELINE north_star: identical detection sets, scores / coords within 1e-3 max '
                                              '(tests/test_gpu_e2e.py::test_north_star_*)' if args.precision == 'f16x2' else
                                              'fp16-storage budget: scores within 5e-3 max, >= 97 % of detections reproduced (tests/test_gpu_e2e.py)'),
@@ -474,20 +487,20 @@ def main():
     head.close()
     single.close()
 
-    def rate(S_, prec, lb, fh, steps=60):
-        hs = Harness(S_, prec, letterbox=lb, from_host=fh)
-        el, _ = hs.measure(steps, 30, min_s=0.25, max_regions=16)     # barrier + max over ranks inside
+    def rate(S_, prec, lb, fh, steps=60, graph=None):
+        hs = Harness(S_, prec, letterbox=lb, from_host=fh, graph=use_graph if graph is None else graph)
+        el, _ = hs.measure(steps, 30, min_s=0.25, max_regions=16)
         hs.close()
-        return round(world * B * steps / el, 1)
+        return round(B * steps / el, 1)
 
     if not args.no_secondary:
         sec = {}
         try:
-            # every rank takes part (host feeding is where the N-GPU curve is expected to bend)
-            sec['from_host_images_per_sec'] = rate(S, args.precision, False, True)
-            sec['from_host_note'] = ('PCIe-inclusive: pinned host u8 frames -> H2D on a copy stream per slot -> run -> decode -> D2H of '
-                                     'detections [32,600,6] + counts; whole job over all ranks; never the headline value')
-            if world == 1:
+            sec['from_host_note'] = ('value_from_host: pinned host u8 frames -> H2D node of the captured step -> run -> decode -> detections '
+                                     'written by the compaction kernel into pinned host memory at their live size (no D2H copy); whole job over all ranks')
+            if world == 1:                                             # single-process extras: never inside a multi-rank barrier
+                sec['eager_images_per_sec'] = rate(S, args.precision, False, False, graph=False)
+                sec['eager_from_host_images_per_sec'] = rate(S, args.precision, False, True, graph=False)
                 sec['letterbox_images_per_sec'] = rate(S, args.precision, True, False)
                 sec['from_host_letterbox_images_per_sec'] = rate(S, args.precision, True, True)
                 other = 'f16x2' if args.precision == 'f16' else 'f16'

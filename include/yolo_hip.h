@@ -199,6 +199,33 @@ int yk_decode_py_ex(const yk_decode_cfg_t *cfg, const float *const *d_pred, int 
                     float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, int32_t *d_box_index,
                     void *stream);
 
+/* The same selection, concatenated ACROSS the batch as well (keras_inference.py:133-135 concatenates per image): rows of image b
+ * are rows[offsets[b] .. offsets[b+1]) (6 floats each, same order as d_dets), offsets[batch] = total.  `rows` (capacity
+ * batch*C*max_out rows), `offsets` [batch+1] and `rows_index` (may be NULL; the box index of every row) may be device memory or
+ * pinned, device-mapped HOST memory (hipHostMalloc): then the detections reach the host at their live size, with no device-to-host
+ * copy whose size would have to be known first.  d_dets / d_counts (device, may be NULL) additionally receive the padded form. */
+int yk_decode_py_packed(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                        float obj_thresh, float iou_thresh, int max_out, float *rows, int32_t *offsets, int32_t *rows_index,
+                        float *d_dets, int32_t *d_counts, void *stream);
+
+/* ---- a step as one hipGraph (the kpu_run_kmodel(..., dma, ai_done_cb) shape of main.c:303-311: submit once, get called back) ----
+ * Everything issued on `stream` (a created stream, not NULL) between yk_graph_begin and yk_graph_end - yk_run_*, yk_decode_py*,
+ * yk_letterbox_u8, yk_memcpy_async - is recorded, not executed; yk_graph_launch replays the recording with ONE host call.
+ * Rules: run the step once eagerly on the same stream first (scratch is allocated on first use, per stream); the replay uses the
+ * pointers, batch and thresholds of the capture; keep the named buffers alive; one replay of a plan at a time.  The capture is
+ * thread-local (other host threads may use HIP meanwhile). */
+typedef struct yk_graph yk_graph_t; /* opaque */
+int yk_graph_begin(void *stream);
+int yk_graph_end(void *stream, yk_graph_t **out);
+int yk_graph_launch(yk_graph_t *g, void *stream);
+int yk_graph_node_count(const yk_graph_t *g);          /* nodes of the recording */
+int yk_graph_kernel_node_count(const yk_graph_t *g);   /* ... of which kernels (the rest: copies / fills) */
+void yk_graph_destroy(yk_graph_t *g);
+/* hipMemcpyAsync(hipMemcpyDefault) on `stream`: the host<->device legs of a captured step (pinned host memory). */
+int yk_memcpy_async(void *dst, const void *src, size_t bytes, void *stream);
+/* Device address of pinned host memory (hipHostGetDevicePointer): the form of a host buffer a kernel can write. */
+int yk_host_device_ptr(void *h_ptr, void **d_ptr);
+
 /* C-mode (region_layer.c:121-283) for a batch of layer outputs without host round trips.
  * d_input element (b, anchor n, entry e, row y, col x) is at
  *   b*stride_b + n*stride_n + e*stride_e + y*stride_y + x*stride_x   (floats)

@@ -370,6 +370,60 @@ __global__ void __launch_bounds__(256) compact_py_kernel(int ntot, int C, int ma
     }
 }
 
+// The same concatenation ACROSS the batch: rows of image b start at offsets[b] (offsets[batch] = total), nothing between the images.
+// `rows` / `offsets` / `box_index` may be device memory or pinned, device-mapped HOST memory: in the second case the detections land on
+// the host at their live size (a few KB) with no device-to-host copy to size or to wait for.  grid (batch), 256 threads.
+__global__ void __launch_bounds__(256) compact_packed_kernel(int ntot, int C, int max_out, int batch, const float4 *__restrict__ boxes,
+                                                            const int *__restrict__ sel_g, const float *__restrict__ sel_s,
+                                                            const int *__restrict__ cnt, float *rows, int *offsets, int *box_index,
+                                                            float *__restrict__ dets, int *__restrict__ counts) {
+    extern __shared__ int base[];                   // [C + 1] exclusive prefix of this image's per-class counts, [C + 1] = rows of the images before it
+    __shared__ int part[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int before = 0;
+    for (int i = tid; i < b * C; i += 256) before += cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = before;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) {
+            base[c] = acc;
+            acc += cnt[b * C + c];
+        }
+        base[C] = acc;
+        const int first = part[0] + part[1] + part[2] + part[3];
+        base[C + 1] = first;
+        offsets[b] = first;
+        if (b == batch - 1) offsets[batch] = first + acc;
+        if (counts) counts[b] = acc;
+    }
+    __syncthreads();
+    const int first = base[C + 1];
+    for (int slot = tid; slot < C * max_out; slot += 256) {
+        const int c = slot / max_out, j = slot - c * max_out;
+        if (j < base[c + 1] - base[c]) {
+            const int g = sel_g[((size_t)b * C + c) * max_out + j];
+            const float4 bb = boxes[(size_t)b * ntot + g];
+            const float sv = sel_s[((size_t)b * C + c) * max_out + j];
+            float *d = rows + ((size_t)first + base[c] + j) * 6;
+            reinterpret_cast<float2 *>(d)[0] = make_float2(bb.x, bb.y);        // rows are 24 bytes: 8-byte aligned
+            reinterpret_cast<float2 *>(d)[1] = make_float2(bb.z, bb.w);
+            reinterpret_cast<float2 *>(d)[2] = make_float2(sv, (float)c);
+            if (box_index) box_index[(size_t)first + base[c] + j] = g;
+            if (dets) {
+                float *e = dets + ((size_t)b * C * max_out + base[c] + j) * 6;
+                e[0] = bb.x; e[1] = bb.y; e[2] = bb.z; e[3] = bb.w; e[4] = sv; e[5] = (float)c;
+            }
+        }
+    }
+}
+
+static int decode_impl(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw, float obj_thresh,
+                       float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, int32_t *d_box_index, float *rows, int32_t *offsets,
+                       int32_t *rows_index, void *stream);
+
 extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
                             float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts,
                             void *stream) {
@@ -379,7 +433,27 @@ extern "C" int yk_decode_py(const yk_decode_cfg_t *cfg, const float *const *d_pr
 extern "C" int yk_decode_py_ex(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
                                float obj_thresh, float iou_thresh, int max_out, float *d_dets, int32_t *d_counts,
                                int32_t *d_box_index, void *stream) {
-    if (!cfg || !d_pred || !d_dets || !d_counts || batch <= 0 || max_out <= 0 || cfg->n_layers <= 0 ||
+    if (!d_dets || !d_counts) {
+        yk_set_error("yk_decode_py: bad argument");
+        return YK_ERR_ARG;
+    }
+    return decode_impl(cfg, d_pred, batch, d_image_hw, obj_thresh, iou_thresh, max_out, d_dets, d_counts, d_box_index, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int yk_decode_py_packed(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw,
+                                   float obj_thresh, float iou_thresh, int max_out, float *rows, int32_t *offsets, int32_t *rows_index,
+                                   float *d_dets, int32_t *d_counts, void *stream) {
+    if (!rows || !offsets) {
+        yk_set_error("yk_decode_py_packed: bad argument");
+        return YK_ERR_ARG;
+    }
+    return decode_impl(cfg, d_pred, batch, d_image_hw, obj_thresh, iou_thresh, max_out, d_dets, d_counts, nullptr, rows, offsets, rows_index, stream);
+}
+
+static int decode_impl(const yk_decode_cfg_t *cfg, const float *const *d_pred, int batch, const float *d_image_hw, float obj_thresh,
+                       float iou_thresh, int max_out, float *d_dets, int32_t *d_counts, int32_t *d_box_index, float *rows, int32_t *offsets,
+                       int32_t *rows_index, void *stream) {
+    if (!cfg || !d_pred || batch <= 0 || max_out <= 0 || cfg->n_layers <= 0 ||
         cfg->n_layers > YK_MAX_LAYERS || cfg->anchor_num <= 0 || cfg->anchor_num > YK_MAX_ANCHORS ||
         cfg->class_num <= 0) {
         yk_set_error("yk_decode_py: bad argument");
@@ -438,8 +512,12 @@ extern "C" int yk_decode_py_ex(const yk_decode_cfg_t *cfg, const float *const *d
     else
         hipLaunchKernelGGL(nms_py_kernel<2048>, dim3(a.C, batch), dim3(64), 0, st, ntot, a.C, obj_thresh, iou_thresh, max_out, boxes, scores_t,
                            sel_g, sel_s, cnt);
-    hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(256), (a.C + 1) * sizeof(int), st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
-                       d_dets, d_counts, d_box_index);
+    if (rows)
+        hipLaunchKernelGGL(compact_packed_kernel, dim3(batch), dim3(256), (a.C + 2) * sizeof(int), st, ntot, a.C, max_out, batch, boxes, sel_g,
+                           sel_s, cnt, rows, offsets, rows_index, d_dets, d_counts);
+    else
+        hipLaunchKernelGGL(compact_py_kernel, dim3(batch), dim3(256), (a.C + 1) * sizeof(int), st, ntot, a.C, max_out, boxes, sel_g, sel_s, cnt,
+                           d_dets, d_counts, d_box_index);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

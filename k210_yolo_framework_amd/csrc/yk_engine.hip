@@ -765,3 +765,99 @@ extern "C" int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t
     if (bytes_per_image) *bytes_per_image = p->L[i].bytes;
     return YK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A step as ONE hipGraph.  Everything issued on `stream` between yk_graph_begin and yk_graph_end (yk_run_*, yk_decode_py*,
+// yk_letterbox_u8, yk_memcpy_async ...) is recorded instead of executed; yk_graph_launch replays it with one host call
+// (the eager step is ~30 launches at 3-4 us of host time each: SURVEY 7 step 8).  The capture is thread-local: other host threads
+// (an input pipeline's producer) may keep allocating and copying on their own streams meanwhile.  A replay uses the pointers and
+// sizes of the capture: the step must have run once eagerly on the same stream before (the decode scratch is allocated on first use
+// and is keyed by stream), the buffers it names must stay alive, and the plan must not be replayed on two streams at once.
+// ---------------------------------------------------------------------------------------------------------------------
+struct yk_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    size_t nodes = 0, kernels = 0;
+};
+
+extern "C" int yk_graph_begin(void *stream) {
+    if (!stream) {
+        yk_set_error("yk_graph_begin: the default stream cannot be captured; pass a created stream");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return YK_OK;
+}
+
+extern "C" int yk_graph_end(void *stream, yk_graph_t **out) {
+    if (!out) {
+        yk_set_error("yk_graph_end: bad argument");
+        return YK_ERR_ARG;
+    }
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    YK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    if (!g) {
+        yk_set_error("yk_graph_end: the capture was invalidated (a call that cannot be captured ran on the stream)");
+        return YK_ERR_HIP;
+    }
+    yk_graph *r = new yk_graph();
+    r->graph = g;
+    hipError_t e = hipGraphInstantiate(&r->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        yk_set_error("yk_graph_end: hipGraphInstantiate -> %s", hipGetErrorString(e));
+        (void)hipGraphDestroy(g);
+        delete r;
+        return YK_ERR_HIP;
+    }
+    if (hipGraphGetNodes(g, nullptr, &r->nodes) == hipSuccess && r->nodes) {
+        std::vector<hipGraphNode_t> nd(r->nodes);
+        size_t n = r->nodes;
+        if (hipGraphGetNodes(g, nd.data(), &n) == hipSuccess)
+            for (size_t i = 0; i < n; ++i) {
+                hipGraphNodeType ty;
+                if (hipGraphNodeGetType(nd[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel) ++r->kernels;
+            }
+    }
+    *out = r;
+    return YK_OK;
+}
+
+extern "C" int yk_graph_launch(yk_graph_t *g, void *stream) {
+    if (!g || !g->exec) {
+        yk_set_error("yk_graph_launch: bad graph");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return YK_OK;
+}
+
+extern "C" int yk_graph_node_count(const yk_graph_t *g) { return g ? (int)g->nodes : 0; }
+extern "C" int yk_graph_kernel_node_count(const yk_graph_t *g) { return g ? (int)g->kernels : 0; }
+
+extern "C" void yk_graph_destroy(yk_graph_t *g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+extern "C" int yk_memcpy_async(void *dst, const void *src, size_t bytes, void *stream) {
+    if (!dst || !src) {
+        yk_set_error("yk_memcpy_async: bad argument");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream));
+    return YK_OK;
+}
+
+// device address of pinned host memory (hipHostMalloc / hipHostRegister'ed): what a kernel must be given to write detections
+// straight into host memory (yk_decode_py_packed)
+extern "C" int yk_host_device_ptr(void *h_ptr, void **d_ptr) {
+    if (!h_ptr || !d_ptr) {
+        yk_set_error("yk_host_device_ptr: bad argument");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipHostGetDevicePointer(d_ptr, h_ptr, 0));
+    return YK_OK;
+}

@@ -52,6 +52,13 @@ void *yk_scratch(int device, void *stream, int slot, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     scratch_buf &b = g_scratch[scratch_key{device, stream, slot}];
     if (b.bytes < bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+            // an allocation cannot be captured, and a graph replays the pointers it was captured with
+            yk_set_error("yk_scratch: stream is capturing and its scratch must grow (%zu > %zu bytes): run the step once eagerly on this stream, at its "
+                         "largest batch, before yk_graph_begin", bytes, b.bytes);
+            return nullptr;
+        }
         if (b.p) {
             (void)hipStreamSynchronize((hipStream_t)stream);
             (void)hipFree(b.p);

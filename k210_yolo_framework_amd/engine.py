@@ -15,7 +15,8 @@ import numpy as np
 
 from . import netspec as ns
 
-LIB_PATH = Path(__file__).resolve().parent / 'csrc' / 'libyolo_hip.so'
+# YK_LIB_PATH: the developer build of the same library (`make -C csrc dev`: tuning switches compiled in), for tools/ only
+LIB_PATH = Path(os.environ.get('YK_LIB_PATH') or Path(__file__).resolve().parent / 'csrc' / 'libyolo_hip.so')
 YK_MAX_LAYERS, YK_MAX_ANCHORS = 4, 8
 PRECISIONS = {'f16': 0, 'f16x2': 1}          # YK_PRECISION_F16 / YK_PRECISION_F16X2
 _lib: Optional[C.CDLL] = None
@@ -68,13 +69,15 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
+                   'yk_graph_begin', 'yk_graph_end', 'yk_graph_launch', 'yk_graph_node_count', 'yk_graph_kernel_node_count', 'yk_memcpy_async', 'yk_host_device_ptr', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
                    'yk_bias_add_f32', 'yk_colsum_f32', 'yk_upsample2x_bwd_f32', 'yk_maxpool2_fwd_f32',
                    'yk_maxpool2_bwd_f32', 'yk_axpy_f32', 'yk_adam_f32', 'yk_dot_f32'):
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
+        L.yk_graph_destroy.restype = None
         _lib = L
     return _lib
 
@@ -311,53 +314,278 @@ def yolo_loss(y_true, y_pred, anchors_l, obj_thresh, iou_thresh, obj_weight, noo
     return loss, grad, ign
 
 
-def letterbox_u8(frames, dst_hw, stream=None):
+def letterbox_u8(frames, dst_hw, stream=None, out=None):
     """GPU Helper._process_img letterbox (tools/utils.py:378-399): cuda uint8 [B,h,w,3] -> cuda uint8 [B,H,W,3]."""
     import torch
     require_gpu()
     assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.shape[-1] == 3
     B, sh, sw, _ = frames.shape
-    out = torch.empty((B, int(dst_hw[0]), int(dst_hw[1]), 3), dtype=torch.uint8, device=frames.device)
+    if out is None:
+        out = torch.empty((B, int(dst_hw[0]), int(dst_hw[1]), 3), dtype=torch.uint8, device=frames.device)
+    assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (B, int(dst_hw[0]), int(dst_hw[1]), 3)
     _check(lib().yk_letterbox_u8(_ptr(frames), C.c_int(B), C.c_int(sh), C.c_int(sw), _ptr(out), C.c_int(out.shape[1]),
                                  C.c_int(out.shape[2]), _stream(stream)), 'yk_letterbox_u8')
     return out
 
 
+class Graph:
+    """A captured step (yk_graph_*, include/yolo_hip.h): one host call replays every launch recorded between begin and end."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+
+    @property
+    def nodes(self) -> int:
+        return int(lib().yk_graph_node_count(self._h)) if self._h else 0
+
+    @property
+    def kernel_nodes(self) -> int:
+        return int(lib().yk_graph_kernel_node_count(self._h)) if self._h else 0
+
+    def launch(self, stream_handle: C.c_void_p) -> None:
+        _check(lib().yk_graph_launch(self._h, stream_handle), 'yk_graph_launch')
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            lib().yk_graph_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def capture(stream_handle: C.c_void_p, issue) -> Graph:
+    """Record what `issue()` submits to the stream as a Graph.  The stream must have run the same step eagerly before."""
+    L = lib()
+    _check(L.yk_graph_begin(stream_handle), 'yk_graph_begin')
+    try:
+        issue()
+    except Exception:
+        h = C.c_void_p()
+        L.yk_graph_end(stream_handle, C.byref(h))                  # leave capture mode whatever happened
+        if h.value:
+            L.yk_graph_destroy(h)
+        raise
+    h = C.c_void_p()
+    _check(L.yk_graph_end(stream_handle, C.byref(h)), 'yk_graph_end')
+    return Graph(h)
+
+
+def _pinned(shape, dtype):
+    """Pinned host tensor + the address a kernel may use for it."""
+    import torch
+    t = torch.empty(shape, dtype=dtype).pin_memory()
+    d = C.c_void_p()
+    _check(lib().yk_host_device_ptr(C.c_void_p(t.data_ptr()), C.byref(d)), 'yk_host_device_ptr')
+    return t, d
+
+
+class Ticket:
+    """One batch submitted from host memory (Pipeline.submit_host).  `result()` waits for it and returns (rows [n,6] float32 =
+    top,left,bottom,right,score,class ; offsets [B+1] int32: image b owns rows[offsets[b]:offsets[b+1]]) - the concatenation of
+    keras_inference.py:133-135, for every image of the batch.  Valid until the slot is reused `depth` submits later."""
+
+    def __init__(self, slot, batch, event, with_index):
+        self._slot, self.batch, self.event, self._with_index = slot, batch, event, with_index
+
+    def result(self):
+        self.event.synchronize()
+        s = self._slot
+        off = s.h_offsets[:self.batch + 1].numpy().copy()
+        n = int(off[-1])
+        rows = s.h_rows[:n].numpy().copy()
+        if self._with_index:
+            return rows, off, s.h_index[:n].numpy().copy()
+        return rows, off
+
+
+class _Slot:
+    pass
+
+
 class Pipeline:
     """Several independent batches in flight on one GPU (the kpu_run_kmodel(async)+callback shape of main.c:303-311, widened).
 
-    One batch alone leaves CUs idle: a step is ~24 dependent launches, most of them a single round of <= 256 workgroups.
+    One batch alone leaves CUs idle: a step is ~27 dependent launches, most of them a single round of <= 256 workgroups.
     `depth` plans, each with its own outputs / split-K slabs, on `depth` HIP streams (decode scratch is per stream inside the
     library) let the GPU interleave workgroups of different batches; nothing is shared between them but the weight values.
-    submit() returns at once; the returned (dets, counts) tensors belong to that slot's stream until the slot is reused
-    `depth` submits later, so consume them (or call `wait`) before that."""
+
+    graph=True (default): a slot's step - (host -> device copy) -> (letterbox) -> yk_run_u8 -> decode + per-class NMS -> results - is
+    captured once as a hipGraph and REPLAYED: one host call per batch instead of ~30 launches.  A captured step is bound to the
+    buffers it was captured with: device frames are replayed in place when they live at an address the slot has already captured
+    (the slot's own `input(i)` buffer, or up to two caller buffers - a resident ring), and are copied into `input(i)` otherwise.
+
+    submit() returns at once; the returned (dets, counts) tensors belong to that slot and are overwritten when the slot is reused
+    `depth` submits later, so consume them (or call `wait`) before that.  submit_host() takes frames from (pinned) host memory and
+    delivers the detections to host memory at their live size; see Ticket."""
 
     def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None,
-                 precision: str = 'f16x2'):
+                 precision: str = 'f16x2', graph: bool = True, src_hw: Optional[Tuple[int, int]] = None, max_out: int = 30):
         import torch
         require_gpu()
         self.depth = max(1, int(depth))
-        self.spec, self.max_batch = spec, int(max_batch)
+        self.spec, self.max_batch, self.graph = spec, int(max_batch), bool(graph)
+        self.src_hw = None if src_hw is None else (int(src_hw[0]), int(src_hw[1]))     # frames of this size are letterboxed on the GPU
+        self.max_out = int(max_out)
         self.plans = [Plan(spec, weights, max_batch=max_batch, device=device, precision=precision) for _ in range(self.depth)]
         self.outs = [p.outputs() for p in self.plans]
+        dev = torch.device(f'cuda:{self.plans[0].device}')
         cur = torch.cuda.current_stream()
         self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
         for s in self.streams:
             s.wait_stream(cur)
         self.cfg = make_decode_cfg(anchors, spec.class_num, spec.in_hw, spec.out_hw())
+        B, H, W = self.max_batch, *spec.in_hw
+        nrow = spec.class_num * self.max_out
+        self.slots = []
+        for i in range(self.depth):
+            s = _Slot()
+            s.plan, s.stream, s.st = self.plans[i], self.streams[i], C.c_void_p(self.streams[i].cuda_stream)
+            s.preds = (C.c_void_p * len(self.outs[i]))(*[C.c_void_p(o.data_ptr()) for o in self.outs[i]])
+            s.frames = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+            s.src = torch.empty((B, *self.src_hw, 3), dtype=torch.uint8, device=dev) if self.src_hw else s.frames
+            s.image_hw = torch.empty((B, 2), dtype=torch.float32, device=dev)
+            s.dets = torch.zeros((B, nrow, 6), dtype=torch.float32, device=dev)
+            s.counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+            s.index = torch.full((B, nrow), -1, dtype=torch.int32, device=dev)
+            s.h_src = s.h_rows = s.h_offsets = s.h_index = None                        # pinned side, built on first submit_host
+            s.graphs = {}
+            s.foreign = []                                                              # caller buffers this slot has captured
+            self.slots.append(s)
         self._n = 0
+        self.host_us = 0.0
 
-    def submit(self, frames_u8, image_hw=None, obj_thresh: float = 0.7, iou_thresh: float = 0.5, max_out: int = 30):
-        """frames_u8: cuda uint8 [B,H,W,3] (must stay alive until the results are consumed).  -> (dets, counts, stream)."""
+    # -- buffers ------------------------------------------------------------------------------------
+    def input(self, i: int):
+        """Slot i's own device input [max_batch, h, w, 3] uint8 (camera size when src_hw is set): fill it, then submit(None)."""
+        return self.slots[i % self.depth].src
+
+    def host_input(self, i: int):
+        """Slot i's pinned host input (same shape as input(i)): fill it, then submit_host(None)."""
+        s = self.slots[i % self.depth]
+        self._host_side(s)
+        return s.h_src
+
+    def next_slot(self) -> int:
+        return self._n % self.depth
+
+    def _host_side(self, s):
         import torch
-        i = self._n % self.depth
+        if s.h_src is None:
+            nrow = self.max_batch * self.spec.class_num * self.max_out
+            s.h_src, _ = _pinned(tuple(s.src.shape), torch.uint8)
+            s.h_rows, s.d_rows = _pinned((nrow, 6), torch.float32)
+            s.h_offsets, s.d_offsets = _pinned((self.max_batch + 1,), torch.int32)
+            s.h_index, s.d_index = _pinned((nrow,), torch.int32)
+            s.h_offsets.zero_()
+
+    # -- the step, as the library calls it is made of (eager, or recorded by capture()) ---------------------------------
+    def _issue(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
+        L = lib()
+        H, W = self.spec.in_hw
+        if host:
+            _check(L.yk_memcpy_async(C.c_void_p(s.src.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()), s.st),
+                   'yk_memcpy_async')
+            src_ptr = s.src.data_ptr()
+        x = src_ptr
+        if self.src_hw:
+            _check(L.yk_letterbox_u8(C.c_void_p(x), C.c_int(B), C.c_int(self.src_hw[0]), C.c_int(self.src_hw[1]), _ptr(s.frames),
+                                     C.c_int(H), C.c_int(W), s.st), 'yk_letterbox_u8')
+            x = s.frames.data_ptr()
+        _check(L.yk_run_u8(s.plan._h, C.c_void_p(x), C.c_int(B), s.st), 'yk_run_u8')
+        ihw = _ptr(s.image_hw) if use_hw else None
+        if host:
+            _check(L.yk_decode_py_packed(C.byref(self.cfg), s.preds, C.c_int(B), ihw, C.c_float(obj), C.c_float(iou), C.c_int(max_out),
+                                         s.d_rows, s.d_offsets, s.d_index if want_index else None, None, None, s.st), 'yk_decode_py_packed')
+        else:
+            _check(L.yk_decode_py_ex(C.byref(self.cfg), s.preds, C.c_int(B), ihw, C.c_float(obj), C.c_float(iou), C.c_int(max_out),
+                                     _ptr(s.dets), _ptr(s.counts), _ptr(s.index) if want_index else None, s.st), 'yk_decode_py_ex')
+
+    def _run(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
+        if max_out > self.max_out:
+            raise YkError(f'max_out {max_out} > the pipeline\'s max_out {self.max_out}')
+        args = (B, src_ptr, host, use_hw, float(obj), float(iou), int(max_out), bool(want_index))
+        if not self.graph:
+            return self._issue(s, *args)
+        g = s.graphs.get(args)
+        if g is None:
+            if not s.graphs or B > max(k[0] for k in s.graphs):
+                self._issue(s, *args)                              # first use (and every larger batch): eager, sizes the per-stream scratch
+                s.stream.synchronize()
+            g = s.graphs[args] = capture(s.st, lambda: self._issue(s, *args))
+        g.launch(s.st)
+
+    def _set_hw(self, s, B, image_hw):
+        import torch
+        if image_hw is None:
+            return False
+        hw = torch.as_tensor(np.broadcast_to(np.asarray(image_hw, np.float32), (B, 2)).copy())
+        with torch.cuda.stream(s.stream):
+            s.image_hw[:B].copy_(hw, non_blocking=False)
+        return True
+
+    def submit(self, frames_u8=None, image_hw=None, obj_thresh: float = 0.7, iou_thresh: float = 0.5, max_out: int = 30,
+               return_index: bool = False, batch: Optional[int] = None, sync_input: bool = True):
+        """frames_u8: cuda uint8 [B,h,w,3] that stays alive until the results are consumed (None: the slot's own input(i) buffer, `batch`
+        images of it).  -> (dets [B, C*max_out, 6], counts [B], stream[, box_index [B, C*max_out]]) - the slot's tensors, sliced to B."""
+        import time
+        import torch
+        t0 = time.perf_counter()
+        s = self.slots[self._n % self.depth]
         self._n += 1
-        st = self.streams[i]
-        st.wait_stream(torch.cuda.current_stream())         # the frames may have been produced on the caller's stream
-        with torch.cuda.stream(st):
-            self.plans[i].run_u8(frames_u8)
-            dets, counts = decode_py(self.cfg, self.outs[i], frames_u8.shape[0], image_hw, obj_thresh, iou_thresh, max_out)
-        return dets, counts, st
+        if frames_u8 is None:
+            B = self.max_batch if batch is None else int(batch)
+            ptr = s.src.data_ptr()
+        else:
+            assert frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+            assert tuple(frames_u8.shape[1:]) == tuple(s.src.shape[1:]), (frames_u8.shape, s.src.shape)
+            B = int(frames_u8.shape[0])
+            if sync_input:
+                s.stream.wait_stream(torch.cuda.current_stream())       # the frames may have been produced on the caller's stream
+            ptr = frames_u8.data_ptr()
+            if self.graph and ptr != s.src.data_ptr() and ptr not in s.foreign:
+                if len(s.foreign) < 2:
+                    s.foreign.append(ptr)                               # a resident caller buffer: replayed in place from now on
+                else:
+                    with torch.cuda.stream(s.stream):
+                        s.src[:B].copy_(frames_u8, non_blocking=True)
+                    ptr = s.src.data_ptr()
+        assert 0 < B <= self.max_batch
+        use_hw = self._set_hw(s, B, image_hw)
+        self._run(s, B, ptr, False, use_hw, obj_thresh, iou_thresh, max_out, return_index)
+        self.host_us = (time.perf_counter() - t0) * 1e6
+        if return_index:
+            return s.dets[:B], s.counts[:B], s.stream, s.index[:B]
+        return s.dets[:B], s.counts[:B], s.stream
+
+    def submit_host(self, frames_u8=None, image_hw=None, obj_thresh: float = 0.7, iou_thresh: float = 0.5, max_out: int = 30,
+                    return_index: bool = False, batch: Optional[int] = None) -> Ticket:
+        """frames_u8: host uint8 [B,h,w,3] (numpy or torch; copied into the slot's pinned buffer) or None = `batch` images already
+        written to host_input(i).  The frames cross PCIe, the detections come back to pinned host memory at their live size."""
+        import time
+        import torch
+        t0 = time.perf_counter()
+        s = self.slots[self._n % self.depth]
+        self._n += 1
+        self._host_side(s)
+        if frames_u8 is None:
+            B = self.max_batch if batch is None else int(batch)
+        else:
+            f = torch.as_tensor(frames_u8)
+            assert f.dtype == torch.uint8 and tuple(f.shape[1:]) == tuple(s.src.shape[1:]), f.shape
+            B = int(f.shape[0])
+            s.stream.synchronize()                                      # the slot's previous batch may still be reading h_src
+            s.h_src[:B].copy_(f)
+        assert 0 < B <= self.max_batch
+        use_hw = self._set_hw(s, B, image_hw)
+        self._run(s, B, None, True, use_hw, obj_thresh, iou_thresh, max_out, return_index)
+        ev = torch.cuda.Event()
+        ev.record(s.stream)
+        self.host_us = (time.perf_counter() - t0) * 1e6
+        return Ticket(s, B, ev, return_index)
 
     def wait(self):
         for s in self.streams:
@@ -365,5 +593,9 @@ class Pipeline:
 
     def close(self):
         self.wait()
+        for s in self.slots:
+            for g in s.graphs.values():
+                g.close()
+            s.graphs = {}
         for p in self.plans:
             p.close()

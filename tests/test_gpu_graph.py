@@ -1,0 +1,153 @@
+"""engine.Pipeline as captured hipGraphs (yk_graph_*): a replayed step gives exactly what the eager step gives, holds nothing but
+kernels (plus ONE host-to-device copy on the from-host path), and the from-host path delivers the reference's concatenated detections
+(keras_inference.py:133-135) to host memory at their live size."""
+import numpy as np
+import pytest
+
+from k210_yolo_framework_amd import netspec as ns
+from k210_yolo_framework_amd.helper import VOC_ANCHORS
+
+pytestmark = pytest.mark.gpu
+
+
+def _net():
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    return spec, spec.init_weights(seed=1)
+
+
+@pytest.mark.parametrize('precision', ['f16x2', 'f16'])
+def test_replayed_step_equals_eager_step_and_is_kernels_only(precision):
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    B = 8
+    g = torch.Generator(device='cuda').manual_seed(11)
+    frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g) for _ in range(4)]
+    eager = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=2, precision=precision, graph=False)
+    want = []
+    for f in frames:
+        d, c, _, i = eager.submit(f, return_index=True)
+        eager.wait()
+        want.append((d.cpu().numpy().copy(), c.cpu().numpy().copy(), i.cpu().numpy().copy()))
+    eager.close()
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=2, precision=precision, graph=True)
+    for rnd in range(3):                                           # round 0 captures, rounds 1-2 replay (two resident buffers per slot)
+        for k in range(0, 4, 2):
+            got = [pipe.submit(f, return_index=True) for f in frames[k:k + 2]]
+            pipe.wait()
+            for (d, c, _, i), (wd, wc, wi) in zip(got, want[k:k + 2]):
+                c = c.cpu().numpy()
+                assert np.array_equal(c, wc)
+                for b in range(B):
+                    assert np.array_equal(d[b, :c[b]].cpu().numpy(), wd[b, :wc[b]]), (rnd, k, b)
+                    assert np.array_equal(i[b, :c[b]].cpu().numpy(), wi[b, :wc[b]])
+    graphs = [g for s in pipe.slots for g in s.graphs.values()]
+    assert len(graphs) == 4                                        # 2 slots x 2 resident caller buffers
+    nl = len(pipe.plans[0].launches())
+    for g in graphs:
+        assert g.nodes == g.kernel_nodes, (g.nodes, g.kernel_nodes)   # no fill / copy node in a device-resident step
+        assert g.nodes >= nl + 3                                   # every launch of the plan + decode, NMS, compaction
+    # a third buffer per slot is copied into the slot's own input and replayed from there: same results
+    extra = frames[0].clone()
+    d, c, _ = pipe.submit(extra)
+    pipe.wait()
+    assert np.array_equal(c.cpu().numpy(), want[0][1])
+    pipe.close()
+
+
+def test_from_host_ticket_delivers_the_concatenated_detections():
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    B = 6
+    rng = np.random.default_rng(5)
+    batches = [rng.integers(0, 256, (B, 224, 320, 3), dtype=np.uint8) for _ in range(3)]
+    hw = np.array([[240, 320], [224, 320], [480, 640], [100, 300], [224, 320], [375, 500]], np.float32)
+    for graph in (False, True):
+        pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=8, depth=2, graph=graph)
+        for rnd in range(2):
+            for f in batches:
+                fd = torch.from_numpy(f).cuda()
+                d, c, _, i = pipe.submit(fd, image_hw=hw, return_index=True)
+                pipe.wait()
+                d, c, i = d.cpu().numpy(), c.cpu().numpy(), i.cpu().numpy()
+                t = pipe.submit_host(f, image_hw=hw, return_index=True)
+                rows, off, idx = t.result()
+                assert off.shape == (B + 1,) and off[0] == 0 and np.array_equal(np.diff(off), c)
+                assert rows.shape == (c.sum(), 6)
+                for b in range(B):
+                    assert np.array_equal(rows[off[b]:off[b + 1]], d[b, :c[b]]), (graph, rnd, b)
+                    assert np.array_equal(idx[off[b]:off[b + 1]], i[b, :c[b]])
+        if graph:
+            host_graphs = [g for s in pipe.slots for k, g in s.graphs.items() if k[2]]
+            assert host_graphs and all(g.nodes == g.kernel_nodes + 1 for g in host_graphs)   # the H2D copy is the only non-kernel node
+        # frames staged by the caller in the slot's pinned buffer: no host-side copy at all
+        i0 = pipe.next_slot()
+        pipe.host_input(i0)[:B].copy_(torch.from_numpy(batches[0]))
+        rows2, off2 = pipe.submit_host(None, batch=B, image_hw=hw).result()
+        d, c, _ = pipe.submit(torch.from_numpy(batches[0]).cuda(), image_hw=hw)
+        pipe.wait()
+        assert np.array_equal(np.diff(off2), c.cpu().numpy())
+        pipe.close()
+
+
+def test_letterboxing_pipeline_equals_letterbox_then_run():
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    B = 4
+    g = torch.Generator(device='cuda').manual_seed(2)
+    cam = torch.randint(0, 256, (B, 240, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
+    plan = engine.Plan(spec, w, max_batch=B)
+    cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
+    plan.run_u8(engine.letterbox_u8(cam, (224, 320)))
+    d0, c0 = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)
+    torch.cuda.synchronize()
+    d0, c0 = d0.cpu().numpy(), c0.cpu().numpy()
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=2, src_hw=(240, 320))
+    for _ in range(3):
+        d, c, _ = pipe.submit(cam)
+        pipe.wait()
+        assert np.array_equal(c.cpu().numpy(), c0)
+        for b in range(B):
+            assert np.array_equal(d[b, :c0[b]].cpu().numpy(), d0[b, :c0[b]])
+    rows, off = pipe.submit_host(cam.cpu().numpy()).result()
+    assert np.array_equal(np.diff(off), c0)
+    pipe.close()
+    plan.close()
+
+
+def test_capture_refuses_a_cold_stream():
+    """A capture cannot allocate: yk_scratch must say so instead of invalidating the recording silently."""
+    import ctypes as C
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    plan = engine.Plan(spec, w, max_batch=2)
+    cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
+    st = torch.cuda.Stream()
+    frames = torch.zeros((2, 224, 320, 3), dtype=torch.uint8, device='cuda')
+    with torch.cuda.stream(st):
+        plan.run_u8(frames)                                              # the network has run on this stream, the decode has not
+        probe = [torch.empty((2, 600, 6), device='cuda'), torch.empty((2,), dtype=torch.int32, device='cuda')]
+        del probe                                                        # torch's own blocks for the decode outputs are cached now
+    torch.cuda.synchronize()
+
+    def issue():
+        with torch.cuda.stream(st):
+            plan.run_u8(frames)
+            engine.decode_py(cfg, plan.outputs(), 2, None, 0.7, 0.5)    # first decode on this stream: needs its scratch
+
+    with pytest.raises(engine.YkError, match='capturing'):
+        engine.capture(C.c_void_p(st.cuda_stream), issue)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):                                          # the stream is usable again, and warm after one eager step
+        plan.run_u8(frames)
+        engine.decode_py(cfg, plan.outputs(), 2, None, 0.7, 0.5)
+    st.synchronize()
+    g = engine.capture(C.c_void_p(st.cuda_stream), issue)
+    assert g.nodes == g.kernel_nodes > 20
+    g.launch(C.c_void_p(st.cuda_stream))
+    st.synchronize()
+    g.close()
+    plan.close()
