@@ -29,6 +29,14 @@ _COLORMAP = [(255, 82, 0), (0, 255, 245), (0, 61, 255), (0, 255, 112), (0, 255, 
              (192, 0, 128), (64, 128, 128), (192, 128, 128), (0, 64, 0), (128, 64, 0), (0, 192, 0), (128, 192, 0), (0, 64, 128)]
 
 
+def write_arguments_to_file(args, filename) -> None:
+    """The `args.txt` dump next to every checkpoint (tools/utils.py:47-50, keras_train.py:23-26,41): one `key: value` line per
+    parsed argument, in declaration order."""
+    lines = [f'{key}: {value}\n' for key, value in vars(args).items()]
+    with open(filename, 'w') as f:
+        f.writelines(lines)
+
+
 class Helper(object):
     """tools/utils.py:53-521: anchors, grid tables, label encode/decode, image reading and letterboxing, dataset iteration."""
 
@@ -61,6 +69,12 @@ class Helper(object):
         """Cell (column, row) that holds a centre given relative to the image (utils.py:156)."""
         h, w = self.out_hw[layer]
         return np.floor(np.asarray(box_xy) * (w, h)).astype(int)
+
+    def _xy_to_grid(self, xy: np.ndarray, layer: int) -> np.ndarray:
+        """Image-relative label centres [out_h, out_w, A, 2] -> position inside their own cell, in cell units (utils.py:107-122): the
+        inverse of `_xy_to_all`."""
+        cells_wh = self.out_hw[layer][::-1]
+        return np.asarray(xy) * cells_wh - self.xy_offset[layer]
 
     @staticmethod
     def _fake_iou(a: np.ndarray, b: np.ndarray):
@@ -313,6 +327,21 @@ def tf_xywh_to_grid(all_true_xy, all_true_wh, layer: int, h: Helper):
     cells_wh = h.out_hw[layer][::-1]
     with np.errstate(divide='ignore'):
         return all_true_xy * cells_wh - h.xy_offset[layer], np.log(all_true_wh / h.anchors[layer])
+
+
+def tf_reshape_box(true_xy_A, true_wh_A, p_xy_A, p_wh_A, layer: int, helper: Helper):
+    """utils.py:575-614: the broadcast shapes the reference's (older) ignore-mask code pairs every prediction with every true box in:
+    true [n,2] -> [B,h,w,A,n,2] and predictions [B,h,w,A,2] -> [B,h,w,A,n,2].  Returned as numpy broadcast VIEWS (the reference
+    materialises them with tf.tile); `helper.batch_size` must be set, as there."""
+    t_xy, t_wh = np.asarray(true_xy_A), np.asarray(true_wh_A)
+    q_xy, q_wh = np.asarray(p_xy_A), np.asarray(p_wh_A)
+    n = t_xy.shape[0]
+    gh, gw = (int(v) for v in helper.out_hw[layer])
+    lead = (int(helper.batch_size), gh, gw, int(helper.anchor_number))
+    if q_xy.shape[:4] != lead:
+        raise ValueError(f'tf_reshape_box: predictions {q_xy.shape} do not match (batch, h, w, anchors) = {lead}')
+    return (np.broadcast_to(t_xy, lead + (n, 2)), np.broadcast_to(t_wh, lead + (n, 2)),
+            np.broadcast_to(q_xy[..., None, :], lead + (n, 2)), np.broadcast_to(q_wh[..., None, :], lead + (n, 2)))
 
 
 def tf_iou(pred_xy, pred_wh, vaild_xy, vaild_wh):

@@ -178,27 +178,12 @@ def load_keras_weights(spec: ns.NetSpec, path, base: Optional[Dict[str, np.ndarr
     return assign(spec, read_keras_h5(path), base=base, strict=strict)
 
 
-def save_keras_weights(spec: ns.NetSpec, weights: Dict[str, np.ndarray], path, tf_keras_names: bool = True) -> None:
-    """Write `weights` in Keras' `save_weights` HDF5 layout (root attribute `layer_names`, one group per layer with `weight_names`).
-    NOTE the format: the reference's keras_train.py:105-109 calls `keras.models.save_model`, whose file additionally carries the
-    architecture (`model_config`) and nests the same tree under `/model_weights`; this writer produces the WEIGHTS-ONLY file - what
-    `model.load_weights(path)` reads on the reference side (keras_inference.py:80 does exactly that), not what `load_model` /
-    `TFLiteConverter.from_keras_model_file` (keras_freeze.py:15-23) need.  The reader (`read_keras_h5`) accepts both layouts.
-    Layers are written in creation order; auto-named layers get tf.keras 1.14 names ('conv2d', 'conv2d_1', ...)."""
+def _weights_tree(spec: ns.NetSpec, weights: Dict[str, np.ndarray], tf_keras_names: bool = True):
+    """The `save_weights` tree: ({layer: ({layer: {weight: array}}, {'weight_names'})}, root attributes)."""
     tree, order = {}, []
-    n_conv = n_bn = 0
-
-    def auto(prefix: str, i: int) -> str:
-        return prefix if (i == 0 and tf_keras_names) else f'{prefix}_{i if tf_keras_names else i + 1}'
-
-    def fixed(name: str) -> bool:
-        return not name.startswith(('head_conv_', 'conv2d_'))
+    names = _file_layer_names(spec, tf_keras_names)
     for l in spec.layers:
-        if fixed(l.name):
-            cname = l.name
-        else:
-            cname = auto('conv2d', n_conv)
-            n_conv += 1
+        cname, bname = names[l.name]
         ws = {('depthwise_kernel:0' if l.kind == 'dwconv' else 'kernel:0'): np.asarray(weights[l.name + '/kernel'], np.float32)}
         wn = [f'{cname}/{"depthwise_kernel" if l.kind == "dwconv" else "kernel"}:0']
         if l.use_bias:
@@ -206,14 +191,136 @@ def save_keras_weights(spec: ns.NetSpec, weights: Dict[str, np.ndarray], path, t
             wn.append(f'{cname}/bias:0')
         tree[cname] = ({cname: ws}, {'weight_names': np.array([w.encode() for w in wn])})
         order.append(cname)
+        if bname:
+            tree[bname] = ({bname: {f'{k}:0': np.asarray(weights[f'{l.bn_name}/{k}'], np.float32) for k in BN_KEYS}},
+                           {'weight_names': np.array([f'{bname}/{k}:0'.encode() for k in BN_KEYS])})
+            order.append(bname)
+    return tree, {'layer_names': np.array([n.encode() for n in order]), 'backend': np.bytes_(b'tensorflow'),
+                  'keras_version': np.bytes_(b'2.2.4-tf')}
+
+
+def save_keras_weights(spec: ns.NetSpec, weights: Dict[str, np.ndarray], path, tf_keras_names: bool = True) -> None:
+    """Write `weights` in Keras' `save_weights` HDF5 layout (root attribute `layer_names`, one group per layer with `weight_names`):
+    the WEIGHTS-ONLY file, what `model.load_weights(path)` reads on the reference side (keras_inference.py:80, keras_train.py:52).
+    The full-model file of keras_train.py:105-109 (`save_model`: the same tree under `/model_weights` plus `model_config`) is
+    `save_keras_model`.  The reader (`read_keras_h5`) accepts both layouts.
+    Layers are written in creation order; auto-named layers get tf.keras 1.14 names ('conv2d', 'conv2d_1', ...)."""
+    tree, attrs = _weights_tree(spec, weights, tf_keras_names)
+    h5lite.write(path, tree, attrs)
+
+
+# ---- the full-model file of keras_train.py:105-109 (`keras.models.save_model(yolo_model, ckpt)`) -------------------------------------
+def keras_model_config(spec: ns.NetSpec) -> dict:
+    """The functional-model description Keras 2.2.4-tf stores in the `model_config` attribute of a `save_model` file, rebuilt from
+    the op list: InputLayer, [ZeroPadding2D +] Conv2D / DepthwiseConv2D, BatchNormalization, LeakyReLU / ReLU, MaxPooling2D,
+    UpSampling2D, Concatenate, Add, with every layer's inbound node.  Weighted layers carry the names `save_keras_weights` writes
+    (creation-order `conv2d_N` / `batch_normalization_N` for the head, the backbone's own names elsewhere); helper layers get derived
+    names (`<conv>_pad`, `<conv>_relu`).  Every layer config lists the constructor arguments that DIFFER from Keras' defaults
+    (`from_config` is `cls(**config)`): the attribute has to fit HDF5's 64 KiB object-header message, which a fully spelled-out
+    Darknet-53 (252 layers) does not."""
+    layers = [{'name': 'input_1', 'class_name': 'InputLayer', 'inbound_nodes': [],
+               'config': {'batch_input_shape': [None, int(spec.in_hw[0]), int(spec.in_hw[1]), 3], 'dtype': 'float32', 'name': 'input_1'}}]
+    producer = {0: 'input_1'}                                   # tensor id -> name of the Keras layer whose output it is
+    names = _file_layer_names(spec)
+    counters = {}
+
+    def fresh(prefix):
+        i = counters.get(prefix, 0)
+        counters[prefix] = i + 1
+        return prefix if i == 0 else f'{prefix}_{i}'
+
+    def add(name, cls, cfg, inbound):
+        layers.append({'name': name, 'class_name': cls, 'config': {'name': name, **cfg}, 'inbound_nodes': [[[src, 0, 0, {}] for src in inbound]]})
+        return name
+    darknet = spec.name in ('yolo', 'tiny_yolo')
+    bn_momentum = 0.999 if spec.name == 'yolo_mobilev2' else 0.99           # keras_mobilenet_v2.py:319; Keras default elsewhere
+    for op in spec.ops:
+        ty, src = op['type'], producer[op['in0']]
+        co = spec.tensors[op['out']][2]
+        if ty in (ns.OP_CONV, ns.OP_DWCONV):
+            l = op['layer']
+            cname, bname = names[l]
+            k, st = op['k'], op['stride']
+            pad = [[int(op['pad_t']), int(op['pad_b'])], [int(op['pad_l']), int(op['pad_r'])]]
+            # the reference pads every strided conv explicitly (ZeroPadding2D + 'valid': keras_mobilenet.py:343,418, keras_mobilenet_v2.py:312,
+            # 455, yolonet.py:197) and uses padding='same' at stride 1
+            same = st == 1 and pad == [[(k - 1) // 2] * 2] * 2
+            if not same and any(v for row in pad for v in row):
+                src = add(f'{cname}_pad', 'ZeroPadding2D', {'padding': pad}, [src])
+            layer = next(x for x in spec.layers if x.name == l)
+            common = {'kernel_size': [k, k], 'strides': [st, st], 'padding': 'same' if same else 'valid', 'use_bias': bool(layer.use_bias)}
+            if ty == ns.OP_CONV:
+                cfg = {**common, 'filters': int(co)}
+                if darknet:
+                    cfg['kernel_regularizer'] = {'class_name': 'L1L2', 'config': {'l1': 0.0, 'l2': 0.0005}}      # yolonet.py:243
+                src = add(cname, 'Conv2D', cfg, [src])
+            else:
+                src = add(cname, 'DepthwiseConv2D', common, [src])
+            if bname:
+                src = add(bname, 'BatchNormalization', {'axis': [3], 'momentum': bn_momentum, 'epsilon': 0.001}, [src])
+            if op['act'] == ns.ACT_LEAKY:
+                src = add(f'{cname}_leaky', 'LeakyReLU', {'alpha': float(np.float32(op['alpha']))}, [src])
+            elif op['act'] in (ns.ACT_RELU, ns.ACT_RELU6):
+                src = add(f'{cname}_relu', 'ReLU', {'max_value': 6.0} if op['act'] == ns.ACT_RELU6 else {}, [src])
+        elif ty == ns.OP_MAXPOOL:
+            src = add(fresh('max_pooling2d'), 'MaxPooling2D', {'pool_size': [2, 2], 'padding': 'same', 'strides': [op['stride']] * 2}, [src])
+        elif ty == ns.OP_UPSAMPLE:
+            src = add(fresh('up_sampling2d'), 'UpSampling2D', {'size': [2, 2]}, [src])
+        elif ty == ns.OP_CONCAT:
+            src = add(fresh('concatenate'), 'Concatenate', {'axis': -1}, [src, producer[op['in1']]])
+        elif ty == ns.OP_ADD:
+            src = add(fresh('add'), 'Add', {}, [src, producer[op['in1']]])
+        else:
+            raise ValueError(f'op type {ty}')
+        producer[op['out']] = src
+    return {'class_name': 'Model', 'config': {'name': 'model', 'layers': layers, 'input_layers': [['input_1', 0, 0]],
+                                              'output_layers': [[producer[t], 0, 0] for t in spec.outputs]}}
+
+
+def _file_layer_names(spec: ns.NetSpec, tf_keras_names: bool = True) -> Dict[str, Tuple[str, Optional[str]]]:
+    """conv layer name of the spec -> (Keras conv layer name, Keras BatchNormalization layer name | None), as save_keras_weights numbers them."""
+    out, n_conv, n_bn = {}, 0, 0
+
+    def auto(prefix: str, i: int) -> str:
+        return prefix if (i == 0 and tf_keras_names) else f'{prefix}_{i if tf_keras_names else i + 1}'
+    for l in spec.layers:
+        fixed = not l.name.startswith(('head_conv_', 'conv2d_'))
+        if fixed:
+            cname = l.name
+        else:
+            cname = auto('conv2d', n_conv)
+            n_conv += 1
+        bname = None
         if l.bn_name:
-            if fixed(l.name):
+            if fixed:
                 bname = keras_bn_name(l)
             else:
                 bname = auto('batch_normalization', n_bn)
                 n_bn += 1
-            tree[bname] = ({bname: {f'{k}:0': np.asarray(weights[f'{l.bn_name}/{k}'], np.float32) for k in BN_KEYS}},
-                           {'weight_names': np.array([f'{bname}/{k}:0'.encode() for k in BN_KEYS])})
-            order.append(bname)
-    h5lite.write(path, tree, {'layer_names': np.array([n.encode() for n in order]), 'backend': np.bytes_(b'tensorflow'),
-                              'keras_version': np.bytes_(b'2.2.4-tf')})
+        out[l.name] = (cname, bname)
+    return out
+
+
+def save_keras_model(spec: ns.NetSpec, weights: Dict[str, np.ndarray], path) -> None:
+    """The file `keras.models.save_model(yolo_model, path)` writes (keras_train.py:105-109; what `load_model`,
+    `TFLiteConverter.from_keras_model_file` (keras_freeze.py:15-23) and `load_weights` all read): root attributes `keras_version`,
+    `backend`, `model_config` (JSON, keras_model_config) and the `save_weights` tree nested under `/model_weights`.  No optimizer
+    state (`include_optimizer` has nothing to include: Adam's moments live in train.Trainer and are not part of the reference's
+    inference hand-off)."""
+    import json
+    tree, attrs = _weights_tree(spec, weights)
+    cfg = json.dumps(keras_model_config(spec), separators=(',', ':')).encode('utf8')
+    h5lite.write(path, {'model_weights': (tree, attrs)},
+                 {'keras_version': np.bytes_(b'2.2.4-tf'), 'backend': np.bytes_(b'tensorflow'), 'model_config': np.bytes_(cfg)})
+
+
+def read_model_config(path) -> Optional[dict]:
+    """`model_config` of a full-model file as a dict (None for a weights-only file)."""
+    import json
+    f = h5lite.File(path)
+    raw = f.attrs.get('model_config')
+    if raw is None:
+        return None
+    if isinstance(raw, np.ndarray):
+        raw = raw.item() if raw.shape == () else raw.ravel()[0]
+    return json.loads(raw.decode('utf8') if isinstance(raw, (bytes, np.bytes_)) else str(raw))

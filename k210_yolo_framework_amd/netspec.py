@@ -77,7 +77,7 @@ class NetSpec:
         y = self._new_tensor(ho, wo, cout)
         self.layers.append(Layer(name, 'conv', (k, k, cin, cout), bias, name + '_bn' if bn else None))
         self.ops.append(dict(type=OP_CONV, in0=x, in1=-1, out=y, cin=cin, cout=cout, k=k, stride=stride,
-                             pad_t=pt, pad_l=pl, act=act[0], alpha=act[1], layer=name,
+                             pad_t=pt, pad_l=pl, pad_b=pb, pad_r=pr, act=act[0], alpha=act[1], layer=name,
                              flags=FLAG_NET_OUTPUT if net_output else 0))
         return y
 
@@ -89,7 +89,7 @@ class NetSpec:
         y = self._new_tensor(ho, wo, c)
         self.layers.append(Layer(name, 'dwconv', (3, 3, c, 1), False, name + '_bn'))
         self.ops.append(dict(type=OP_DWCONV, in0=x, in1=-1, out=y, cin=c, cout=c, k=3, stride=stride,
-                             pad_t=pt, pad_l=pl, act=act[0], alpha=act[1], layer=name, flags=0))
+                             pad_t=pt, pad_l=pl, pad_b=pb, pad_r=pr, act=act[0], alpha=act[1], layer=name, flags=0))
         return y
 
     def maxpool(self, x: int, stride: int) -> int:

@@ -22,7 +22,7 @@ from pathlib import Path
 import numpy as np
 
 from . import engine, netspec
-from .helper import ERROR, INFO, Helper
+from .helper import ERROR, INFO, Helper, write_arguments_to_file
 
 
 def synthetic_list(n: int, in_hw, class_num: int, seed: int):
@@ -84,9 +84,7 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
     log_dir = Path(log_dir) / datetime.strftime(datetime.now(), '%Y%m%d-%H%M%S')
     if rank == 0:
         log_dir.mkdir(parents=True, exist_ok=True)
-        with open(log_dir / 'args.txt', 'w') as f:
-            for k, v in vars(args).items():
-                f.write(f'{k}: {v}\n')
+        write_arguments_to_file(args, str(log_dir / 'args.txt'))                # keras_train.py:41
     in_hw, out_hw = np.reshape(np.array(image_size), (-1, 2)), np.reshape(np.array(output_size), (-1, 2))
     anchors = f'data/{train_set}_anchor.npy'
     if synthetic:
@@ -152,7 +150,7 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
         from . import keras_io
         ckpt = log_dir / 'yolo_model.h5'                                        # keras_train.py:105-109
         final = tr.export_weights()
-        keras_io.save_keras_weights(spec, final, str(ckpt))
+        keras_io.save_keras_model(spec, final, str(ckpt))                      # save_model layout: /model_weights + model_config
         np.savez(log_dir / 'yolo_model.npz', **final)
         print()
         print(INFO, f' Save Model as {str(ckpt)}')

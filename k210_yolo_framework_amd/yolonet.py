@@ -92,9 +92,15 @@ class YoloModel:
             have = {**self._s['weights'], **have}
         self.set_weights(have)
 
+    def save(self, path: str) -> None:
+        """`keras.models.save_model(yolo_model, path)` (keras_train.py:105-109): the full-model HDF5 file - `model_config` (the
+        architecture as Keras JSON) plus the weights under `/model_weights`."""
+        from . import keras_io
+        keras_io.save_keras_model(self.spec, self._s['weights'], str(path))
+
     def save_weights(self, path: str) -> None:
-        """The checkpoint of keras_train.py:105-109, weights only: `.h5` -> Keras `save_weights` layout (what the reference's
-        `load_weights` reads; not a `save_model` file with `model_config`), else `.npz`."""
+        """Weights only: `.h5` -> Keras `save_weights` layout (what the reference's `load_weights` reads), else `.npz`.  The full-model
+        file of keras_train.py:105-109 is `save`."""
         path = str(path)
         if path.endswith(('.h5', '.hdf5')):
             from . import keras_io

@@ -148,3 +148,94 @@ print('h5py-ok')
 """
     r = subprocess.run([H5PY_PYTHON, '-W', 'ignore', '-c', code], capture_output=True, text=True)
     assert 'h5py-ok' in r.stdout, r.stderr[-2000:]
+
+
+# ---- the full-model file of keras_train.py:105-109 ------------------------------------------------------------------------------------
+def _walk_shapes(cfg: dict):
+    """Shape inference over a Keras functional `model_config` (channels_last): {layer name: (h, w, c)}."""
+    out = {}
+    for l in cfg['config']['layers']:
+        c, cls = l['config'], l['class_name']
+        src = [out[n[0]] for n in l['inbound_nodes'][0]] if l['inbound_nodes'] else []
+        if cls == 'InputLayer':
+            out[l['name']] = tuple(c['batch_input_shape'][1:])
+            continue
+        h, w, ch = src[0]
+        if cls == 'ZeroPadding2D':
+            (pt, pb), (pl, pr) = c['padding']
+            out[l['name']] = (h + pt + pb, w + pl + pr, ch)
+        elif cls in ('Conv2D', 'DepthwiseConv2D', 'MaxPooling2D'):
+            k = c.get('kernel_size', c.get('pool_size'))[0]
+            st = c['strides'][0]
+            if c.get('padding', 'valid') == 'same':
+                ho, wo = -(-h // st), -(-w // st)
+            else:
+                ho, wo = (h - k) // st + 1, (w - k) // st + 1
+            out[l['name']] = (ho, wo, c['filters'] if cls == 'Conv2D' else ch)
+        elif cls == 'UpSampling2D':
+            out[l['name']] = (2 * h, 2 * w, ch)
+        elif cls == 'Concatenate':
+            assert all(s[:2] == src[0][:2] for s in src)
+            out[l['name']] = (h, w, sum(s[2] for s in src))
+        elif cls == 'Add':
+            assert all(s == src[0] for s in src)
+            out[l['name']] = src[0]
+        elif cls in ('BatchNormalization', 'LeakyReLU', 'ReLU'):
+            out[l['name']] = src[0]
+        else:
+            raise AssertionError(cls)
+    return out
+
+
+@pytest.mark.parametrize('name,shape,alpha', [('yolo_mobilev1', (224, 320, 3), 0.75), ('yolo_mobilev2', (224, 320, 3), 1.0),
+                                              ('tiny_yolo', (416, 416, 3), 1.0), ('yolo', (416, 416, 3), 1.0)])
+def test_save_model_layout_round_trip(tmp_path, name, shape, alpha):
+    """keras.models.save_model's file: `model_config` + `/model_weights` (keras_train.py:105-109).  The weights come back bit for bit
+    through the nested layout, and the generated architecture is a consistent Keras functional graph whose shapes are the network's."""
+    from k210_yolo_framework_amd import keras_io, netspec as ns
+    spec = ns.NETWORKS[name](shape, 3, 20, alpha=alpha)
+    w = spec.init_weights(seed=3)
+    path = tmp_path / 'yolo_model.h5'
+    keras_io.save_keras_model(spec, w, path)
+    f = h5lite.File(path)
+    assert 'model_weights' in f and 'layer_names' not in f.attrs and 'layer_names' in f['model_weights'].attrs
+    assert bytes(np.asarray(f.attrs['keras_version']).item()).startswith(b'2.2.4')
+    got, rep = keras_io.load_keras_weights(spec, path)
+    assert set(got) == set(w) and all(np.array_equal(got[k], w[k]) for k in w)
+    cfg = keras_io.read_model_config(path)
+    assert cfg['class_name'] == 'Model'
+    layers = cfg['config']['layers']
+    names = [l['name'] for l in layers]
+    assert len(set(names)) == len(names)                                          # Keras requires unique layer names
+    seen = set()
+    for l in layers:                                                              # topological order, every inbound layer defined before use
+        for node in l['inbound_nodes']:
+            for src, ni, ti, kw in node:
+                assert src in seen and ni == 0 and ti == 0 and kw == {}
+        seen.add(l['name'])
+    file_layers = [n.decode() if isinstance(n, bytes) else str(n) for n in np.asarray(f['model_weights'].attrs['layer_names']).ravel()]
+    weighted = [l['name'] for l in layers if l['class_name'] in ('Conv2D', 'DepthwiseConv2D', 'BatchNormalization')]
+    assert sorted(weighted) == sorted(file_layers)                               # every weighted layer of the graph has its group, and vice versa
+    shapes = _walk_shapes(cfg)
+    outs = [shapes[o[0]] for o in cfg['config']['output_layers']]
+    assert outs == [spec.tensors[t] for t in spec.outputs]
+    n_conv = sum(1 for l in layers if l['class_name'] in ('Conv2D', 'DepthwiseConv2D'))
+    assert n_conv == spec.conv_layer_count()
+    if name == 'yolo_mobilev1':                                                   # spot checks against models/keras_mobilenet.py:340-436
+        by = {l['name']: l for l in layers}
+        assert by['conv1']['config']['padding'] == 'valid' and by['conv1_pad']['config']['padding'] == [[1, 1], [1, 1]]     # :343
+        assert by['conv_dw_1']['class_name'] == 'DepthwiseConv2D' and by['conv_dw_1']['config']['padding'] == 'same'
+        assert by['conv_pw_1_leaky']['config']['alpha'] == pytest.approx(0.3) and 'max_value' not in by['conv_dw_1_relu']['config']
+        assert by['conv1_bn']['config']['epsilon'] == 0.001
+
+
+def test_plugin_save_writes_the_full_model_file(tmp_path):
+    from k210_yolo_framework_amd import keras_io, yolonet
+    m, _ = yolonet.yolo_mobilev1((64, 96, 3), 3, 20, alpha=0.5)
+    m.save(str(tmp_path / 'm.h5'))
+    assert keras_io.read_model_config(tmp_path / 'm.h5')['config']['layers'][0]['config']['batch_input_shape'] == [None, 64, 96, 3]
+    m.save_weights(str(tmp_path / 'w.h5'))
+    assert keras_io.read_model_config(tmp_path / 'w.h5') is None
+    m2, _ = yolonet.yolo_mobilev1((64, 96, 3), 3, 20, alpha=0.5)
+    m2.load_weights(str(tmp_path / 'm.h5'))
+    assert all(np.array_equal(m2.get_weights()[k], v) for k, v in m.get_weights().items())

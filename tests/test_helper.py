@@ -229,3 +229,40 @@ def test_read_img_equals_real_skimage_imread_for_every_pil_mode():
         got = h._read_img(os.path.join(here, 'imread', name))
         assert got.dtype == exp[name].dtype and got.shape == exp[name].shape, name
         assert np.array_equal(got, exp[name]), name
+
+
+def test_xy_to_grid_is_the_inverse_of_xy_to_all_on_a_known_cell():
+    """utils.py:107-122: image-relative centre -> offset inside its cell.  (0.53, 0.47) on the 14x20 grid lies in column 10, row 6,
+    0.6 of a cell from its left edge and 0.58 from its top."""
+    h = _h()
+    xy = np.zeros((14, 20, 3, 2), np.float32)
+    xy[6, 10, :, :] = (0.53, 0.47)
+    g = h._xy_to_grid(xy, 1)
+    assert g.shape == (14, 20, 3, 2)
+    assert np.allclose(g[6, 10, 0], [0.53 * 20 - 10, 0.47 * 14 - 6]) and np.allclose(g[6, 10, 0], [0.6, 0.58], atol=1e-6)
+    assert np.allclose(g[0, 0, 0], [0, 0]) and np.allclose(g[3, 5, 1], [-5, -3])           # empty cells: minus their own offset
+
+
+def test_tf_reshape_box_pairs_every_prediction_with_every_true_box():
+    """utils.py:575-614: shapes [B,h,w,A,n,2] on both sides, values repeated, nothing copied."""
+    from k210_yolo_framework_amd.helper import tf_reshape_box
+    h = _h()
+    h.batch_size = 2
+    rng = np.random.default_rng(0)
+    t_xy, t_wh = rng.uniform(size=(5, 2)), rng.uniform(size=(5, 2))
+    p_xy, p_wh = rng.uniform(size=(2, 7, 10, 3, 2)), rng.uniform(size=(2, 7, 10, 3, 2))
+    tc, tw, pc, pw = tf_reshape_box(t_xy, t_wh, p_xy, p_wh, 0, h)
+    assert tc.shape == tw.shape == pc.shape == pw.shape == (2, 7, 10, 3, 5, 2)
+    assert np.array_equal(tc[1, 6, 9, 2], t_xy) and np.array_equal(tw[0, 0, 0, 0], t_wh)
+    assert np.array_equal(pc[1, 3, 4, 2, 4], p_xy[1, 3, 4, 2]) and np.array_equal(pw[0, 6, 9, 0, 0], p_wh[0, 6, 9, 0])
+    with pytest.raises(ValueError):
+        tf_reshape_box(t_xy, t_wh, p_xy[:1], p_wh[:1], 0, h)
+
+
+def test_write_arguments_to_file(tmp_path):
+    """keras_train.py:23-26,41: `key: value` per line, declaration order."""
+    import argparse
+    from k210_yolo_framework_amd.helper import write_arguments_to_file
+    ns_ = argparse.Namespace(train_set='voc', batch_size=16, image_size=[224, 320], pre_ckpt=None)
+    write_arguments_to_file(ns_, str(tmp_path / 'args.txt'))
+    assert (tmp_path / 'args.txt').read_text() == 'train_set: voc\nbatch_size: 16\nimage_size: [224, 320]\npre_ckpt: None\n'
