@@ -157,6 +157,10 @@ int yk_run_f32(yk_plan_t *p, const float *d_input, int batch, void *stream);
  * NHWC fp32 [max_batch][h][w][A*(5+C)] (rows beyond the last run's batch are stale). */
 int yk_get_output(yk_plan_t *p, int idx, float **d_ptr, size_t *bytes, int *h, int *w, int *c);
 
+/* Synchronises the device and returns an error if an earlier asynchronous run of this plan failed ON the device (the f16x2 mode's
+ * persistent stage bounds every inter-workgroup wait and gives up rather than hang: then this call says so).  YK_OK otherwise. */
+int yk_plan_check(yk_plan_t *p);
+
 /* Debug/parity access to any intermediate activation (fp16, channel pitch padded
  * to a multiple of 8): copies tensor `tid` of the last run to host as fp32 NHWC. */
 int yk_debug_read_tensor(yk_plan_t *p, int tid, int batch, float *h_dst, size_t dst_elems);

@@ -745,6 +745,19 @@ extern "C" int yk_debug_phase_stamps(yk_plan_t *p, int li, const uint8_t *d_fram
     return YK_OK;
 }
 
+// Waits for the device and reports a sticky device-side failure of an earlier run of this plan (today: the persistent late-backbone
+// stage of the f16x2 mode could not assemble a workgroup cluster; see yk_xpersist.h).  YK_OK otherwise.
+extern "C" int yk_plan_check(yk_plan_t *p) {
+    if (!p) {
+        yk_set_error("yk_plan_check: bad argument");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipSetDevice(p->device));
+    if (p->x) return yk_xplan_check(p->x);
+    YK_HIP(hipDeviceSynchronize());
+    return YK_OK;
+}
+
 extern "C" int yk_plan_launch_count(const yk_plan_t *p) { return !p ? 0 : (p->x ? yk_xplan_launch_count(p->x) : (int)p->L.size()); }
 
 extern "C" int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, double *flops_per_image,

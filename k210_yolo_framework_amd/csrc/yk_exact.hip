@@ -714,6 +714,7 @@ void xdw_geometry(xdw_args &d, int max_batch) {
 }
 
 #include "yk_xblock.h"
+#include "yk_xpersist.h"
 
 // =====================================================================================================================
 // stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once.
@@ -926,7 +927,7 @@ float x_h2f(uint16_t u) {
     return (float)h;
 }
 
-enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK };
+enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK, XK_PERSIST };
 enum { XT_REAL = 0, XT_UP = 1, XT_CAT = 2 };
 // tile configurations of xg_kernel
 enum { XC_64x64 = 0, XC_64x128, XC_128x64, XC_128x128, XC_NUM };
@@ -955,6 +956,9 @@ struct xlaunch {
     int Ho = 0, Wo = 0;
     int cfg = 0, ns = 2;               // xg_kernel tile configuration and ring depth
     unsigned lds = 0;
+    int in_tid = -1, out_tid = -1;     // tensors of a plain depthwise / 1x1 conv launch (chain detection of the persistent stage)
+    xp_args pa;                        // XK_PERSIST
+    int p_cw = 0;
     std::string name;
     double flops = 0, bytes = 0;
 };
@@ -1116,7 +1120,9 @@ struct yk_xplan {
     std::vector<void *> allocs;
     std::vector<int> outputs;
     unsigned *d_imgmax = nullptr;
-    uint32_t *d_amax = nullptr;        // [n_tensors][max_batch][XS]
+    uint32_t *d_amax = nullptr;        // [n_tensors][max_batch][XS], then [max_batch] cluster arrival counters: cleared by every step's first launch
+    size_t zero_words = 0;
+    uint32_t *d_err = nullptr;         // sticky device error word (persistent stage: a cluster barrier timed out)
     int *d_eexp = nullptr;             // [n_tensors][max_batch]
     long long *d_dbg = nullptr;        // developer instrumentation (yk_xplan_phase_stamps)
     int dbg_launch = -1;
@@ -1147,6 +1153,176 @@ void yk_xplan_destroy(yk_xplan *p) {
     if (!p) return;
     for (void *q : p->allocs) (void)hipFree(q);
     delete p;
+}
+
+
+// The late backbone as one persistent launch (yk_xpersist.h).  Looks for the longest run of launches
+//     dw3x3 -> conv1x1 -> dw3x3 -> conv1x1 ...      (plain launches, every one the only consumer of its predecessor's output
+// unless that output is also a tap - then it is additionally written in the stored layout) whose images are small enough for one
+// workgroup's LDS, and replaces it.  The decision depends on the network and the image size only, never on the batch.
+static int x_build_persist(yk_xplan *p, int max_batch) {
+    constexpr int CW = 8;
+    const unsigned ring_cap = XP_NS * 8 * 6 * 1024;
+    auto pw_ok = [&](const xlaunch &l) {
+        const xg_args &g = l.c;
+        return l.kind == XK_CONV && g.ks == 1 && g.stride == 1 && !g.s1.p && !g.up0 && !g.res.p && g.splitk == 1 && g.out && l.in_tid >= 0 &&
+               (g.N % (8 * CW)) == 0 && (g.s0.G % CW) == 0 && (g.s0.G % 4) == 0;
+    };
+    auto dw_ok = [&](const xlaunch &l) { return l.kind == XK_DW && (l.d.in.G % CW) == 0 && (l.d.in.G % 4) == 0; };
+    auto y_fits = [&](int H, int W, int Gs) { return (unsigned)(2 * (H + 2) * (W + 2) * Gs * 16) <= ring_cap; };
+    int best0 = -1, best1 = -1;
+    const int n = (int)p->L.size();
+    for (int i = 0; i < n; ++i) {
+        if (!dw_ok(p->L[i])) continue;
+        int k = i, blocks = 0;
+        while (k + 1 < n && dw_ok(p->L[k]) && pw_ok(p->L[k + 1]) && p->L[k + 1].in_tid == p->L[k].out_tid && p->T[p->L[k].out_tid].uses == 1) {
+            const xdw_args &d = p->L[k].d;
+            const xg_args &g = p->L[k + 1].c;
+            const int nrb = (d.Ho * d.Wo + 15) / 16, ncb = g.N / 16 / CW, nT = 2 * (nrb + ncb);
+            bool ok = nT <= 48 && y_fits(d.in.H, d.in.W, d.in.G / CW) && y_fits(d.Ho, d.Wo, g.N / 8 / CW) && d.in.H * d.in.W <= 1024;
+            bool tile = false;
+            for (int wr = 8; wr >= 1 && !tile; wr >>= 1) tile = (nrb + wr - 1) / wr <= 3 && (ncb + 8 / wr - 1) / (8 / wr) <= 3;
+            if (!ok || !tile) break;
+            ++blocks;
+            k += 2;
+            if (!(k < n && dw_ok(p->L[k]) && p->L[k].in_tid == p->L[k - 1].out_tid)) break;
+        }
+        if (blocks >= 2 && blocks * 2 > best1 - best0 + 1) {
+            best0 = i;
+            best1 = i + 2 * blocks - 1;
+        }
+        if (blocks) i = i + 2 * blocks - 1;
+    }
+    if (best0 < 0) return YK_OK;
+    std::vector<xp_phase> ph;
+    std::vector<std::pair<uint32_t, const xlaunch *>> wcopy;           // arena offset <- launch weights
+    uint32_t arena = 0, dmax = 0;
+    double flops = 0, bytes = 0;
+    int nbar = 0, dbuf = 0;
+    auto zero_phase = [] {
+        xp_phase q;
+        memset(&q, 0, sizeof(q));
+        return q;
+    };
+    for (int k = best0; k <= best1; k += 2) {
+        const xlaunch &ld = p->L[k], &lp = p->L[k + 1];
+        const xdw_args &d = ld.d;
+        const xg_args &g = lp.c;
+        flops += ld.flops + lp.flops;
+        bytes += ld.bytes + lp.bytes;
+        const int Gs_in = d.in.G / CW, Gs_out = g.N / 8 / CW;
+        if (k == best0) {                                              // the chain's input: a stored tensor
+            xp_phase q = zero_phase();
+            q.type = XP_LOAD;
+            q.H = d.in.H; q.W = d.in.W; q.Gs = Gs_in;
+            q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
+            q.src = d.in.p; q.src_eexp = d.in.eexp; q.src_amax = d.in.amax; q.tG = d.in.G;
+            ph.push_back(q);
+        }
+        {
+            xp_phase q = zero_phase();
+            q.type = XP_DW;
+            q.H = d.in.H; q.W = d.in.W; q.Gs = Gs_in;
+            q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
+            q.Ho = d.Ho; q.Wo = d.Wo; q.stride = d.stride; q.pad_t = d.pad_t; q.pad_l = d.pad_l;
+            q.fd_wo = yk_make_fastdiv((uint32_t)q.Wo);
+            q.par = d.par; q.Cp = d.in.G * 8;
+            q.slope = d.slope; q.cap = d.cap; q.gain = d.gain; q.off = d.off;
+            q.nrb_out = (d.Ho * d.Wo + 15) / 16;
+            q.dbuf = dbuf;
+            q.barrier_after = 1;
+            dmax = std::max(dmax, (uint32_t)q.nrb_out * (uint32_t)(d.in.G / 4) * 2048u);
+            ph.push_back(q);
+            ++nbar;
+        }
+        {
+            xp_phase q = zero_phase();
+            q.type = XP_PW;
+            q.H = d.Ho; q.W = d.Wo; q.Gs = Gs_out;
+            q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
+            q.nrb = (d.Ho * d.Wo + 15) / 16; q.nks = d.in.G / 4; q.ncb = g.N / 16 / CW; q.nslab = g.nslab;
+            int bt = 100;
+            for (int wr = 8; wr >= 1; wr >>= 1) {
+                const int tr = (q.nrb + wr - 1) / wr, tc = (q.ncb + 8 / wr - 1) / (8 / wr);
+                if (tr <= 3 && tc <= 3 && tr * tc < bt) {
+                    bt = tr * tc;
+                    q.WR = wr; q.WC = 8 / wr;
+                }
+            }
+            q.ppw = std::max(3, (2 * (q.nrb + q.ncb) + 7) / 8);
+            // one wave per 16-pixel block and the y image + a weight ring fit side by side: fragments straight to registers
+            q.adirect = (q.WC == 1 && q.ncb <= 3 && 2 * (q.H + 2) * (q.W + 2) * q.Gs * 16 <= XP_YB_BYTES) ? (2 * q.ncb + 7) / 8 : 0;
+            q.zero_border = 1;
+            q.w_off = arena;
+            wcopy.push_back({arena, &lp});
+            arena += (g.w_bytes + 1023u) & ~1023u;
+            q.scale = g.scale; q.bias = g.bias;
+            q.pslope = g.slope; q.pcap = g.cap; q.pgain = g.gain0; q.poff = g.off;
+            q.dbuf = dbuf;
+            ph.push_back(q);
+            dbuf ^= 1;
+        }
+        const bool last = k + 1 == best1;
+        p->T[ld.out_tid].d = nullptr;                                  // the depthwise tensor lives in the arena, in MFMA tile order
+        if (!(last || p->T[lp.out_tid].uses != 1)) p->T[lp.out_tid].d = nullptr;   // never leaves the CU
+        if (last || p->T[lp.out_tid].uses != 1) {                      // other kernels read it: stored layout too
+            xp_phase q = zero_phase();
+            q.type = XP_STORE;
+            q.H = d.Ho; q.W = d.Wo; q.Gs = Gs_out;
+            q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
+            q.dst = g.out; q.dst_eexp = g.eexp_out; q.dst_amax = g.amax_out; q.tG = g.outG;
+            ph.push_back(q);
+        }
+    }
+    if ((int)ph.size() > XP_MAXPH) return YK_OK;                       // (keeps the plain launches)
+    for (size_t i = 0; i < ph.size(); ++i) {                           // every LOAD / PW phase requests the parameters of the depthwise phase behind it
+        if (ph[i].type != XP_LOAD && ph[i].type != XP_PW) continue;
+        for (size_t k = i + 1; k < ph.size(); ++k)
+            if (ph[k].type == XP_DW) {
+                ph[i].nd_par = ph[k].par;
+                ph[i].nd_Cp = ph[k].Cp;
+                ph[i].nd_Gs = ph[k].Gs;
+                break;
+            } else if (ph[k].type == XP_PW || ph[k].type == XP_LOAD) {
+                break;
+            }
+    }
+    xlaunch l;
+    l.kind = XK_PERSIST;
+    l.p_cw = CW;
+    xp_args &a = l.pa;
+    memset(&a, 0, sizeof(a));
+    a.d_img_stride = dmax;
+    a.d_off[0] = arena;
+    a.d_off[1] = arena + dmax * (uint32_t)max_batch;
+    const size_t total = (size_t)arena + 2 * (size_t)dmax * max_batch;
+    if (total + 65536 >= X_OOB) return YK_OK;
+    void *ar = nullptr, *dph = nullptr, *pm = nullptr, *px = nullptr;
+    int rc = x_alloc(p, &ar, total + 65536);
+    if (rc) return rc;
+    for (auto &wc : wcopy) YK_HIP(hipMemcpy((uint8_t *)ar + wc.first, wc.second->c.w, wc.second->c.w_bytes, hipMemcpyDeviceToDevice));
+    if ((rc = x_upload(p, &dph, ph.data(), ph.size() * sizeof(xp_phase)))) return rc;
+    if ((rc = x_alloc(p, &pm, sizeof(float) * XP_MAXPH * (size_t)max_batch * CW))) return rc;
+    a.ph = (const xp_phase *)dph;
+    a.n_phase = (int)ph.size();
+    a.CW = CW;
+    a.arena = (const uint8_t *)ar;
+    a.arena_bytes = (uint32_t)total;
+    a.cnt = p->d_amax + (p->zero_words - (size_t)max_batch);
+    a.pmax = (float *)pm;
+    if ((rc = x_alloc(p, &px, sizeof(uint32_t) * (size_t)max_batch * CW))) return rc;
+    a.pxcc = (uint32_t *)px;
+    a.err = p->d_err;
+    char nm[160];
+    const xdw_args &d0 = p->L[best0].d;
+    snprintf(nm, sizeof nm, "x:persist[%d blocks dw3x3+conv1x1 from %dx%dx%d,%d phases,%d cluster barriers,%d wg/image]", (best1 - best0 + 1) / 2, d0.in.H, d0.in.W,
+             d0.in.G * 8, (int)ph.size(), nbar, CW);
+    l.name = nm;
+    l.flops = flops;
+    l.bytes = bytes;
+    p->L.erase(p->L.begin() + best0, p->L.begin() + best1 + 1);
+    p->L.insert(p->L.begin() + best0, l);
+    return YK_OK;
 }
 
 int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors, const float *blob,
@@ -1279,7 +1455,9 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * (size_t)n_tensors * max_batch * XS))) return fail(rc);
+    p->zero_words = (size_t)n_tensors * max_batch * XS + (size_t)max_batch;
+    if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
+    if ((rc = x_alloc(p, (void **)&p->d_err, 256))) return fail(rc);
     if ((rc = x_alloc(p, (void **)&p->d_eexp, sizeof(int) * (size_t)n_tensors * max_batch))) return fail(rc);
     auto amax_of = [&](int tid) { return p->d_amax + (size_t)tid * max_batch * XS; };
     auto eexp_of = [&](int tid) { return p->d_eexp + (size_t)tid * max_batch; };
@@ -1600,6 +1778,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             yk_act_params(o[YK_F_ACT], alpha, &g.slope, &g.cap);
             g.fd_hw = yk_make_fastdiv((uint32_t)(Y.h * Y.w));
             g.fd_wo = yk_make_fastdiv((uint32_t)Y.w);
+            l.in_tid = (S1 || up0) ? -1 : s0;
             xtens *dst = &Y;
             int dst_id = yid;
             if (add_of[i] >= 0) {
@@ -1616,6 +1795,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 g.outG = dst->cp >> 3;
                 g.eexp_out = eexp_of(dst_id);
                 g.amax_out = amax_of(dst_id);
+                l.out_tid = dst_id;
             }
             if (!g.out && !g.out32) {
                 yk_set_error("op %d: output tensor not allocated", i);
@@ -1652,6 +1832,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             d.eexp_out = eexp_of(yid);
             d.amax_out = amax_of(yid);
             xdw_geometry(d, max_batch);
+            l.in_tid = xid;
+            l.out_tid = yid;
             l.lds = (unsigned)((size_t)d.n16p * 32);
             snprintf(nm, sizeof nm, "x:dw3x3s%d_%d[%dx%dx%d]", d.stride, c, d.TH, d.TW, d.GS * 8);
             l.flops = 2.0 * Y.h * Y.w * 9 * c;
@@ -1696,6 +1878,9 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         l.name = nm;
         p->L.push_back(l);
     }
+    if (yk_env_flag("YK_PERSIST", true) && !yk_dev_env("YK_X_NOPERSIST")) {
+        if ((rc = x_build_persist(p, max_batch))) return fail(rc);
+    }
     for (int t : p->outputs)
         if (!p->T[t].d32 || !p->T[t].net_out) {
             yk_set_error("yk_plan_create: output tensor %d is not produced by a NET_OUTPUT conv", t);
@@ -1714,7 +1899,7 @@ __global__ void __launch_bounds__(256) xzero_kernel(uint32_t *__restrict__ z, si
 
 int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream_t st, hipEvent_t *ev) {
     // the per-image running maxima are cleared by the step's first launch (no fill launch, nothing but kernels in a captured step)
-    const size_t amax_words = p->T.size() * (size_t)p->max_batch * XS;
+    const size_t amax_words = p->zero_words;
     int li = 0;
     for (xlaunch &l : p->L) {
         if (ev) YK_HIP(hipEventRecord(ev[2 * li], st));
@@ -1761,6 +1946,19 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             d.B = batch;
             if (const char *e = yk_dev_env("YK_X_DWDBG")) d.dbg = atoi(e);
             hipLaunchKernelGGL(xdw_kernel, dim3((unsigned)(batch * d.tiles_x * d.tiles_y * d.gsl)), dim3((unsigned)((d.NT + 63) & ~63)), l.lds, st, d);
+        } break;
+        case XK_PERSIST: {
+            xp_args pa = l.pa;
+            pa.B = batch;
+            pa.n_cluster = 8 * std::min(4, (batch + 7) / 8);           // <= 32 clusters of p_cw workgroups: one workgroup per CU
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(XP_NS * 8 * 6 * 1024 + XP_MISC));
+                once = true;
+            }
+            pa.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
+            if (const char *e = yk_dev_env("YK_XP_DBG")) pa.dbg = atoi(e);
+            hipLaunchKernelGGL(xp_kernel, dim3((unsigned)(pa.n_cluster * l.p_cw)), dim3(XP_NT), XP_NS * 8 * 6 * 1024 + XP_MISC, st, pa);
         } break;
         case XK_POOL: {
             xpool_args q = l.p;
@@ -1822,7 +2020,7 @@ int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t d
 
 // dev instrumentation: arm phase timestamps for launch `li` (a fused block), run once, copy out [n_wg][16] ticks (100 MHz)
 int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipStream_t st, long long *h_out, int max_wg) {
-    if (li < 0 || li >= (int)p->L.size() || p->L[li].kind != XK_BLOCK) return YK_ERR_ARG;
+    if (li < 0 || li >= (int)p->L.size() || (p->L[li].kind != XK_BLOCK && p->L[li].kind != XK_PERSIST)) return YK_ERR_ARG;
     const size_t cap = 65536;
     if (!p->d_dbg) {
         int rc = x_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 16 * cap);
@@ -1835,6 +2033,18 @@ int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipS
     if (rc) return rc;
     YK_HIP(hipStreamSynchronize(st));
     YK_HIP(hipMemcpy(h_out, p->d_dbg, sizeof(long long) * 16 * std::min<size_t>(cap, (size_t)max_wg), hipMemcpyDeviceToHost));
+    return YK_OK;
+}
+
+// sticky device-side error (a cluster barrier of the persistent stage gave up): synchronises the device
+int yk_xplan_check(yk_xplan *p) {
+    uint32_t e = 0;
+    YK_HIP(hipDeviceSynchronize());
+    YK_HIP(hipMemcpy(&e, p->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e) {
+        yk_set_error("f16x2 persistent stage: a workgroup cluster did not assemble (its workgroups were not co-resident); results of that run are invalid");
+        return YK_ERR_HIP;
+    }
     return YK_OK;
 }
 

@@ -69,7 +69,7 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_check', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
                    'yk_graph_begin', 'yk_graph_end', 'yk_graph_launch', 'yk_graph_node_count', 'yk_graph_kernel_node_count', 'yk_memcpy_async', 'yk_host_device_ptr', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
@@ -174,6 +174,10 @@ class Plan:
         assert x.is_cuda and x.dtype.__str__() == 'torch.float32' and x.is_contiguous()
         assert tuple(x.shape[1:]) == (*self.spec.in_hw, 3), x.shape
         _check(lib().yk_run_f32(self._h, _ptr(x), C.c_int(x.shape[0]), _stream(stream)), 'yk_run_f32')
+
+    def check(self) -> None:
+        """Wait for the device; raise if an earlier asynchronous run of this plan failed on the device (yk_plan_check)."""
+        _check(lib().yk_plan_check(self._h), 'yk_plan_check')
 
     def output_ptrs(self) -> List[Tuple[int, Tuple[int, int, int]]]:
         res = []
