@@ -1251,7 +1251,14 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
             }
             q.ppw = std::max(3, (2 * (q.nrb + q.ncb) + 7) / 8);
             // one wave per 16-pixel block and the y image + a weight ring fit side by side: fragments straight to registers
-            q.adirect = (q.WC == 1 && q.ncb <= 3 && 2 * (q.H + 2) * (q.W + 2) * q.Gs * 16 <= XP_YB_BYTES) ? (2 * q.ncb + 7) / 8 : 0;
+            q.adirect = 0;
+            if (2 * (q.H + 2) * (q.W + 2) * q.Gs * 16 <= XP_YB_BYTES) {
+                if (q.nrb <= 24 && q.ncb == 3) q.adirect = 1;              // kernel instantiations: see xp_kernel
+                else if (q.nrb <= 24 && q.ncb == 2) q.adirect = 3;
+                if ((q.adirect == 1 || q.adirect == 3) && q.nks * q.ncb * 2048 <= 76 * 1024) q.resident = 1;
+                else if (q.nrb == 5 && q.ncb <= 8) q.adirect = 2;
+                else if (q.nrb == 5 && q.ncb <= 16) q.adirect = 4;
+            }
             q.zero_border = 1;
             q.w_off = arena;
             wcopy.push_back({arena, &lp});
@@ -1275,6 +1282,23 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
         }
     }
     if ((int)ph.size() > XP_MAXPH) return YK_OK;                       // (keeps the plain launches)
+    for (size_t i = 0; i + 1 < ph.size(); ++i)                         // a depthwise phase requests the weights of a resident pointwise phase behind it
+        if (ph[i].type == XP_DW && ph[i + 1].type == XP_PW && ph[i + 1].resident) {
+            ph[i].nw_off = ph[i + 1].w_off;
+            ph[i].nw_nks = ph[i + 1].nks;
+            ph[i].nw_ncb = ph[i + 1].ncb;
+            ph[i].nw_nslab = ph[i + 1].nslab;
+            ph[i + 1].resident = 2;
+        }
+    {   // the y image's border must be cleared where its shape changes or something else has used its LDS (the LDS-ring form)
+        int ph_h = -1, ph_w = -1, ph_g = -1;
+        for (auto &q : ph) {
+            if (q.type == XP_LOAD) { ph_h = q.H; ph_w = q.W; ph_g = q.Gs; }
+            if (q.type != XP_PW) continue;
+            q.zero_border = !(q.adirect && q.H == ph_h && q.W == ph_w && q.Gs == ph_g);
+            ph_h = q.H; ph_w = q.W; ph_g = q.Gs;
+        }
+    }
     for (size_t i = 0; i < ph.size(); ++i) {                           // every LOAD / PW phase requests the parameters of the depthwise phase behind it
         if (ph[i].type != XP_LOAD && ph[i].type != XP_PW) continue;
         for (size_t k = i + 1; k < ph.size(); ++k)
@@ -1297,19 +1321,17 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
     a.d_off[1] = arena + dmax * (uint32_t)max_batch;
     const size_t total = (size_t)arena + 2 * (size_t)dmax * max_batch;
     if (total + 65536 >= X_OOB) return YK_OK;
-    void *ar = nullptr, *dph = nullptr, *pm = nullptr, *px = nullptr;
+    void *ar = nullptr, *dph = nullptr, *px = nullptr;
     int rc = x_alloc(p, &ar, total + 65536);
     if (rc) return rc;
     for (auto &wc : wcopy) YK_HIP(hipMemcpy((uint8_t *)ar + wc.first, wc.second->c.w, wc.second->c.w_bytes, hipMemcpyDeviceToDevice));
     if ((rc = x_upload(p, &dph, ph.data(), ph.size() * sizeof(xp_phase)))) return rc;
-    if ((rc = x_alloc(p, &pm, sizeof(float) * XP_MAXPH * (size_t)max_batch * CW))) return rc;
     a.ph = (const xp_phase *)dph;
     a.n_phase = (int)ph.size();
     a.CW = CW;
     a.arena = (const uint8_t *)ar;
     a.arena_bytes = (uint32_t)total;
-    a.cnt = p->d_amax + (p->zero_words - (size_t)max_batch);
-    a.pmax = (float *)pm;
+    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - (size_t)max_batch * CW * 2));
     if ((rc = x_alloc(p, &px, sizeof(uint32_t) * (size_t)max_batch * CW))) return rc;
     a.pxcc = (uint32_t *)px;
     a.err = p->d_err;
@@ -1455,7 +1477,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    p->zero_words = (size_t)n_tensors * max_batch * XS + (size_t)max_batch;
+    p->zero_words = (size_t)n_tensors * max_batch * XS + (size_t)max_batch * 8 * 2;   // + the persistent stage's barrier granules
     if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
     if ((rc = x_alloc(p, (void **)&p->d_err, 256))) return fail(rc);
     if ((rc = x_alloc(p, (void **)&p->d_eexp, sizeof(int) * (size_t)n_tensors * max_batch))) return fail(rc);

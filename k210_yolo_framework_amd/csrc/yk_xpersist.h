@@ -60,6 +60,10 @@ struct xp_phase {
     // the depthwise phase that follows a LOAD / PW phase: its parameter slice is requested while this phase runs
     const float *nd_par;
     int nd_Cp, nd_Gs;
+    int resident;                      // XP_PW: the workgroup's whole weight slice is deposited in LDS before the K loop (1), by the phase before it (2)
+    // XP_DW: the resident pointwise phase behind it - its weight slice is requested before the cluster barrier and lands under it
+    uint32_t nw_off;
+    int nw_nks, nw_ncb, nw_nslab;
     int adirect;                       // XP_PW: every 16-pixel block belongs to one wave (WC == 1): its D fragments go straight to registers
     int zero_border;                   // XP_PW: the y image changes shape here
 };
@@ -69,8 +73,7 @@ struct xp_args {
     int n_phase, B, CW, n_cluster;
     const uint8_t *arena;              // pointwise weights + the two D buffers: one buffer descriptor
     uint32_t arena_bytes, d_off[2], d_img_stride;
-    uint32_t *cnt;                     // [max_batch] arrivals per image (cleared by the step's first launch)
-    float *pmax;                       // [XP_MAXPH][max_batch][CW]
+    unsigned long long *gran;          // [max_batch][CW] {barrier ordinal : 32 | float bits of the member's maximum : 32}, cleared by the step's first launch
     uint32_t *pxcc;                    // [max_batch][CW] XCD id of every member + 1
     uint32_t *err;                     // sticky: a cluster barrier timed out
     long long *stamps;                 // developer builds: [workgroup][4 * XP_MAXPH + 4] wall_clock64 ticks (100 MHz), or null
@@ -90,23 +93,35 @@ __device__ __forceinline__ void xp_store16_plain(const __amdgpu_buffer_rsrc_t rs
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
 }
 
-// Every workgroup of the image has finished the phase and its stores are visible: arrive, poll, acquire (see the header).
-__device__ __forceinline__ bool xp_cluster_barrier(uint32_t *cnt, uint32_t target, uint32_t *err) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its write-through stores
+// Every workgroup of the image has finished the phase and its stores are visible.  The data is the flag (guideline 16, R2): a member
+// publishes ONE 8-byte granule {ordinal of this barrier, the maximum of what it wrote}; lanes 0..CW-1 of wave 0 re-read the image's CW
+// granules (one 64-byte line) until every tag carries the ordinal - no counter, no returning atomic, and the maxima arrive with the
+// last tag.  Returns the image's maximum.
+__device__ __forceinline__ float xp_cluster_barrier(unsigned long long *gran, int CW, int j, uint32_t ordinal, float wg_max, uint32_t *s_max, uint32_t *err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(gran + j, ((unsigned long long)ordinal << 32) | __float_as_uint(wg_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        unsigned long long x = 0;
+        for (;;) {
+            x = lane < CW ? __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)ordinal << 32);
+            if (__all((uint32_t)(x >> 32) == ordinal)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 23)) {                               // ~1 s: the members are not co-resident
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1u << 22)) {                               // ~1 s: the members are not co-resident
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
+        uint32_t m = lane < CW ? (uint32_t)x : 0u;                    // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0) s_max[1] = m;
     }
     __syncthreads();
-    return true;
+    return __uint_as_float(s_max[1]);
 }
 
 // LDS image of y: fp32, a zero border of one pixel, two planes (channels 0-3 | 4-7 of every group) so that the 16-byte reads of
@@ -204,6 +219,8 @@ __device__ __forceinline__ void xp_store(const xp_phase &P, int b, int j, float 
     if (threadIdx.x == 0 && s_max[0]) x_amax_global(P.dst_amax + (size_t)b * XS, s_max[0]);
 }
 
+__device__ __forceinline__ void xp_preload_weights(const xp_args &a, uint32_t w_off, int nks, int ncb, int nslab, int j);
+
 // ---- XP_DW: depthwise 3x3 on y -> D (the next pointwise conv's pixel operand, MFMA tile order, write-through) ----------------
 // returns the storage exponent of D; the workgroup's maximum of |z| goes to *wg_max
 __device__ __forceinline__ int xp_dw(const xp_args &a, const xp_phase &P, int b, int j, float ay, bool same_xcd, uint32_t *s_max, float *wg_max) {
@@ -216,6 +233,8 @@ __device__ __forceinline__ int xp_dw(const xp_args &a, const xp_phase &P, int b,
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.arena, 0, a.arena_bytes, 0x00020000);
     const uint32_t dimg = a.d_off[P.dbuf] + (uint32_t)b * a.d_img_stride;
     if (tid == 0) s_max[0] = 0u;
+    // the next pointwise phase's weights do not depend on anybody: copied to LDS under this pass
+    if (P.nw_nks) xp_preload_weights(a, P.nw_off, P.nw_nks, P.nw_ncb, P.nw_nslab, j);
     float mx = 0.f;
     if (tid < NTd) {
         const int p0 = (int)x_div((uint32_t)tid, P.fd_gs), gl = tid - p0 * Gs;
@@ -450,152 +469,278 @@ __device__ __forceinline__ void xp_pw(const xp_args &a, const xp_phase &P, int b
 }
 
 
-// ---- XP_PW, WC == 1: the pixel operand never touches LDS ---------------------------------------------------------------
-// With one wave per 16-pixel block nothing is shared: a D fragment is used by exactly one wave, so staging it in LDS costs an LDS-DMA
-// write and a ds_read for nothing and makes every ring stage 36 KB (measured: the K loop was bound by the 48 LDS-DMA issues + 96 KB of
-// LDS reads per step behind one barrier, 0.8 us per step; profiles/r04_persist_phases.txt).  Here a wave loads ITS row blocks' fragments
-// straight into registers (D is stored in fragment order: the lane's 16 bytes sit at piece + foff - a fully coalesced 1 KB load), two
-// steps ahead, three register sets; only the weights (6 pieces per step, shared by all waves) go through a small LDS ring.  The y
-// image no longer shares LDS with a ring.
-constexpr int XP_YB_BYTES = 88 * 1024, XP_BRING = XP_YB_BYTES;        // [y image][weight ring 3 x 16 KB] ... [misc]
-template <int NR, int NC, int PB>
-__device__ __forceinline__ void xp_pw_direct_loop(const __amdgpu_buffer_rsrc_t rs, uint32_t dimg, int nks, int nrb, const int (&rb)[3], const int (&cb)[3],
-                                                  int foff, int wid, int lane, const uint32_t (&wb)[2], uint32_t wkstr, floatx4 (&acc)[3][3]) {
-    // No LDS-DMA inside this loop: beside one, hipcc waits vmcnt(0) before the first use of ANY register a plain load filled (it drained
-    // the two-steps-ahead fragment loads every step); with plain loads only it counts exactly.  The weight pieces therefore travel
-    // global -> register (three steps ahead) -> ds_write (one step ahead of their use) -> fragment reads.
-    constexpr int STG = 8 * PB * 1024;
-    half8 Ah[3][NR], Al[3][NR];
-    u32x4 Br[3][PB];
-    auto loadA = [&](half8 (&h)[NR], half8 (&l)[NR], int ks) {
+// ---- XP_PW, one operand private to each wave: it never touches LDS ---------------------------------------------------------
+// In a tile grid of nrb 16-pixel blocks x ncb 16-channel blocks either every pixel block belongs to ONE wave (14x20 pixels, 48 channels
+// per workgroup: 18 x 3, wave w owns pixel blocks w, w+8, w+16 and all three channel blocks) or every channel block does (7x10 pixels, 96
+// channels: 5 x 6, wave w < 6 owns channel block w and all five pixel blocks).  The OWN operand's fragments are used by one wave only:
+// staging them in LDS costs an LDS-DMA write and a ds_read for nothing and makes a ring stage 36 KB (measured: the K loop was bound by
+// 48 LDS-DMA issues + 96 KB of LDS reads per step behind one barrier, 0.8 us per step; profiles/r04_persist_phases.txt).  Here a wave
+// loads its own fragments straight into registers (both operands are stored in fragment order: the lane's 16 bytes sit at piece + foff, a
+// fully coalesced 1 KB load), two steps ahead, three register sets; the SHARED operand (a few pieces per step) is staged through a
+// small LDS ring.  The y image no longer shares LDS with a ring.
+// No LDS-DMA inside the loop: beside one, hipcc waits vmcnt(0) before the first use of ANY register a plain load filled (it drained the
+// two-steps-ahead fragment loads every step); with plain loads only it counts exactly.  The shared pieces therefore travel
+// global -> register (three steps ahead) -> ds_write (one step ahead of their use) -> fragment reads.
+constexpr int XP_YB_BYTES = 68 * 1024, XP_BRING = XP_YB_BYTES;        // [y image][shared-operand ring 3 x 8*PS KB] ... [misc]
+template <int NO, int NSH, int PS, bool OWNPIX>
+__device__ __forceinline__ void xp_pw_direct_loop(const __amdgpu_buffer_rsrc_t rs, int nks, const uint32_t (&own_base)[3], uint32_t own_kstr,
+                                                  const uint32_t (&sh_base)[2], uint32_t sh_kstr, int foff, int wid, int lane, floatx4 (&acc)[NO][NSH], int dbg) {
+    (void)dbg;
+    constexpr int STG = 8 * PS * 1024;
+    half8 Oh[3][NO], Ol[3][NO];
+    u32x4 Sr[3][PS];
+    auto loadO = [&](half8 (&h)[NO], half8 (&l)[NO], int ks) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const uint32_t off = ks < nks ? dimg + (uint32_t)((ks * nrb + rb[i]) * 2) * 1024u + (uint32_t)foff : X_OOB;
+        for (int i = 0; i < NO; ++i) {
+            const uint32_t off = ks < nks ? own_base[i] + (uint32_t)ks * own_kstr + (uint32_t)foff : X_OOB;
+            // the pixel operand was written by other CUs during this launch: sc1 (served by the L2, never by this CU's L1)
+            if constexpr (OWNPIX) {
+                h[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+                l[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024u, 0, 16));
+            } else {
+                h[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                l[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024u, 0, 0));
+            }
+        }
+    };
+    auto loadS = [&](u32x4 (&r)[PS], int ks) {
+#pragma unroll
+        for (int t = 0; t < PS; ++t) {
+            const uint32_t off = ks < nks ? sh_base[t] + (uint32_t)ks * sh_kstr + lane * 16u : X_OOB;
+            if constexpr (OWNPIX) {
+                r[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            } else {
+                r[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+            }
+        }
+    };
+    auto writeS = [&](const u32x4 (&r)[PS], int st) {
+#pragma unroll
+        for (int t = 0; t < PS; ++t) *reinterpret_cast<u32x4 *>(xsm + XP_BRING + st * STG + (wid + 8 * t) * 1024 + lane * 16) = r[t];
+    };
+    auto mma = [&](const half8 &w, const half8 &x, floatx4 &c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0); };
+    half8 sh[NSH], sl_[NSH];                                          // the shared operand's fragments of the CURRENT step, read one step early
+    auto readS = [&](int st) {
+        const unsigned char *Ss = xsm + XP_BRING + st * STG;
+#pragma unroll
+        for (int jj = 0; jj < NSH; ++jj) {
+            sh[jj] = *reinterpret_cast<const half8 *>(Ss + jj * 2048 + foff);
+            sl_[jj] = *reinterpret_cast<const half8 *>(Ss + jj * 2048 + 1024 + foff);
+        }
+    };
+    // step ks (st = ks % 3).  On entry every operand of the step is in registers: own fragments (requested at ks-2), shared fragments
+    // (read from LDS at the end of ks-1) - the matrix pipe starts right behind the barrier.  In its shadow: the shared pieces of ks+2 go
+    // to LDS (they are read at the end of ks+1), requests for the shared pieces of ks+4 and the own fragments of ks+2, and at the end the
+    // LDS reads for ks+1.  Three products per tile as three sweeps over the accumulators (consecutive MFMAs never share one):
+    // w_lo x_hi, w_hi x_lo, w_hi x_hi.
+    auto step = [&](half8 (&ch)[NO], half8 (&cl)[NO], half8 (&nh)[NO], half8 (&nl)[NO], const u32x4 (&sw)[PS], u32x4 (&sld)[PS], int ks, int st) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the fragment reads of ks, this wave's ds_writes of ks-1
+        __builtin_amdgcn_s_barrier();                                 // the pieces of ks+1 are in LDS; stage (ks+2)%3 has been read by everybody
+        asm volatile("" ::: "memory");
+        writeS(sw, st == 0 ? 2 : st - 1);                             // pieces of ks+2
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NSH; ++jj) {
+                if constexpr (OWNPIX) mma(sl_[jj], ch[i], acc[i][jj]);
+                else mma(cl[i], sh[jj], acc[i][jj]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        loadS(sld, ks + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NSH; ++jj) {
+                if constexpr (OWNPIX) mma(sh[jj], cl[i], acc[i][jj]);
+                else mma(ch[i], sl_[jj], acc[i][jj]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        loadO(nh, nl, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NSH; ++jj) {
+                if constexpr (OWNPIX) mma(sh[jj], ch[i], acc[i][jj]);
+                else mma(ch[i], sh[jj], acc[i][jj]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        readS(st == 2 ? 0 : st + 1);                                  // fragments of ks+1
+    };
+    loadS(Sr[0], 0);
+    loadS(Sr[1], 1);
+    loadO(Oh[0], Ol[0], 0);
+    loadS(Sr[2], 2);
+    loadO(Oh[1], Ol[1], 1);
+    writeS(Sr[0], 0);
+    writeS(Sr[1], 1);
+    loadS(Sr[0], 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    readS(0);
+    for (int kt = 0; kt < nks; kt += 3) {                             // steps past nks multiply zeros (out-of-range loads)
+        // (own set of ks, own set for ks+2, pieces written = ks+2, pieces requested = ks+4 into the set ks+1 has vacated)
+        step(Oh[0], Ol[0], Oh[2], Ol[2], Sr[2], Sr[1], kt, 0);
+        step(Oh[1], Ol[1], Oh[0], Ol[0], Sr[0], Sr[2], kt + 1, 1);
+        step(Oh[2], Ol[2], Oh[1], Ol[1], Sr[1], Sr[0], kt + 2, 2);
+    }
+}
+
+// The same with the shared operand RESIDENT: when the workgroup's whole weight slice (nks x NSH x 2 KB) fits in LDS beside the y image,
+// it is deposited once (LDS-DMA, before the loop) and the K loop has no staging, no barrier and no lockstep at all: a wave streams its own
+// fragments two steps ahead and reads the step's weight fragments from LDS.  (Measured before: with per-step staging the loop ran at
+// 0.65 us per step even with the MFMAs and the fragment loads knocked out - the staged pieces' load latency, two steps deep, set the pace.)
+// NKS > 0: the k-step count is a compile-time constant and the loop is unrolled completely - in straight-line code hipcc's wait counts
+// are exact; around a loop with register sets rotating through it, it put a vmcnt(0) at the head of every iteration.
+template <int NO, int NSH, int NKS>
+__device__ __forceinline__ void xp_pw_resident_loop(const __amdgpu_buffer_rsrc_t rs, int nks_rt, const uint32_t (&own_base)[3], uint32_t own_kstr, int foff,
+                                                    floatx4 (&acc)[NO][NSH], int dbg) {
+    (void)dbg;
+    const int nks = NKS > 0 ? NKS : nks_rt;
+    half8 Oh[3][NO], Ol[3][NO];
+    auto loadO = [&](half8 (&h)[NO], half8 (&l)[NO], int ks) {
+#pragma unroll
+        for (int i = 0; i < NO; ++i) {
+            const uint32_t off = ks < nks ? own_base[i] + (uint32_t)ks * own_kstr + (uint32_t)foff : X_OOB;
             h[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
             l[i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024u, 0, 16));
         }
     };
-    auto loadB = [&](u32x4 (&r)[PB], int ks) {
+    auto mma = [&](const half8 &w, const half8 &x, floatx4 &c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0); };
+    auto step = [&](half8 (&ch)[NO], half8 (&cl)[NO], half8 (&nh)[NO], half8 (&nl)[NO], int ks) {
+        const unsigned char *Ws = xsm + XP_BRING + (ks < nks ? ks : 0) * (NSH * 2048);
+        half8 wh[NSH], wl[NSH];
 #pragma unroll
-        for (int t = 0; t < PB; ++t) {
-            const uint32_t off = ks < nks ? wb[t] + (uint32_t)ks * wkstr + lane * 16u : X_OOB;
-            r[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-        }
-    };
-    auto writeB = [&](const u32x4 (&r)[PB], int st) {
-#pragma unroll
-        for (int t = 0; t < PB; ++t) *reinterpret_cast<u32x4 *>(xsm + XP_BRING + st * STG + (wid + 8 * t) * 1024 + lane * 16) = r[t];
-    };
-    // step ks (st = ks % 3): weights of ks+1 -> LDS, fragments of ks (requested at ks-2) x weights of ks (written at ks-1), requests for
-    // the weights of ks+3 and the fragments of ks+2 in the shadow of the sweeps
-    auto step = [&](half8 (&ch)[NR], half8 (&cl)[NR], half8 (&nh)[NR], half8 (&nl)[NR], const u32x4 (&bw)[PB], u32x4 (&bl)[PB], int ks, int st) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's ds_writes of step ks-1
-        __builtin_amdgcn_s_barrier();                                 // everybody's: the weights of ks are in LDS; stage (ks+1)%3 is free
-        asm volatile("" ::: "memory");
-        writeB(bw, st == 2 ? 0 : st + 1);
-        const unsigned char *Bs = xsm + XP_BRING + st * STG;
-        half8 wh[NC], wl[NC];
-#pragma unroll
-        for (int jj = 0; jj < NC; ++jj) {
-            wh[jj] = *reinterpret_cast<const half8 *>(Bs + cb[jj] * 2048 + foff);
-            wl[jj] = *reinterpret_cast<const half8 *>(Bs + cb[jj] * 2048 + 1024 + foff);
+        for (int jj = 0; jj < NSH; ++jj) {
+            wh[jj] = *reinterpret_cast<const half8 *>(Ws + jj * 2048 + foff);
+            wl[jj] = *reinterpret_cast<const half8 *>(Ws + jj * 2048 + 1024 + foff);
         }
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
+        for (int i = 0; i < NO; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NC; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], ch[i], acc[i][jj], 0, 0, 0);
+            for (int jj = 0; jj < NSH; ++jj) mma(wl[jj], ch[i], acc[i][jj]);
         __builtin_amdgcn_sched_barrier(0);
-        loadB(bl, ks + 3);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NC; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], cl[i], acc[i][jj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        loadA(nh, nl, ks + 2);
+        loadO(nh, nl, ks + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
+        for (int i = 0; i < NO; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NC; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], ch[i], acc[i][jj], 0, 0, 0);
+            for (int jj = 0; jj < NSH; ++jj) mma(wh[jj], cl[i], acc[i][jj]);
+#pragma unroll
+        for (int i = 0; i < NO; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NSH; ++jj) mma(wh[jj], ch[i], acc[i][jj]);
     };
-    loadB(Br[0], 0);
-    loadA(Ah[0], Al[0], 0);
-    loadB(Br[1], 1);
-    loadA(Ah[1], Al[1], 1);
-    loadB(Br[2], 2);
-    writeB(Br[0], 0);
-    for (int kt = 0; kt < nks; kt += 3) {                             // steps past nks multiply zeros (out-of-range loads)
-        step(Ah[0], Al[0], Ah[2], Al[2], Br[1], Br[0], kt, 0);
-        step(Ah[1], Al[1], Ah[0], Al[0], Br[2], Br[1], kt + 1, 1);
-        step(Ah[2], Al[2], Ah[1], Al[1], Br[0], Br[2], kt + 2, 2);
+    loadO(Oh[0], Ol[0], 0);
+    loadO(Oh[1], Ol[1], 1);
+    if constexpr (NKS > 0) {
+#pragma unroll
+        for (int kt = 0; kt < NKS; kt += 3) {
+            step(Oh[0], Ol[0], Oh[2], Ol[2], kt);
+            step(Oh[1], Ol[1], Oh[0], Ol[0], kt + 1);
+            step(Oh[2], Ol[2], Oh[1], Ol[1], kt + 2);
+        }
+    } else {
+        for (int kt = 0; kt < nks; kt += 3) {                         // steps past nks multiply zeros (out-of-range fragment loads)
+            step(Oh[0], Ol[0], Oh[2], Ol[2], kt);
+            step(Oh[1], Ol[1], Oh[0], Ol[0], kt + 1);
+            step(Oh[2], Ol[2], Oh[1], Ol[1], kt + 2);
+        }
     }
 }
 
-template <int PB>
-__device__ __forceinline__ void xp_pw_direct(const xp_args &a, const xp_phase &P, int b, int j, int e_in, int pi) {
+// The workgroup's weight slice of a pointwise phase -> LDS (piece p = (k-step, channel block, hi|lo) at p KB); wave w deposits
+// p = w, w+8, ...  Issued by the DEPTHWISE phase before it, in inline assembly: hipcc must not know about these LDS-DMAs, or it parks a
+// vmcnt(0) in front of the depthwise pass's first LDS read (it cannot tell the y image from the weight region) and the copy, instead
+// of running under the pass, is waited for.  The consumer waits for it explicitly (vmcnt(0) + barrier at the head of the pointwise phase).
+// M0 (the LDS-DMA destination) is compiler-reserved: saved, set and restored inside one statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void xp_glds16_asm(const uint8_t *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void xp_preload_weights(const xp_args &a, uint32_t w_off, int nks, int ncb, int nslab, int j) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (P.nd_par) xp_fetch_par(P.nd_par, P.nd_Cp, P.nd_Gs, j);
+    const int np = nks * ncb * 2, per = 2 * ncb;
+    const uint32_t lds0 = (uint32_t)(unsigned long)(lds_ptr_t)(xsm + XP_BRING);
+    for (int p = wid; p < np; p += 8) {
+        const int ks = p / per, r = p - ks * per;
+        const uint8_t *src = a.arena + (size_t)w_off + (size_t)ks * (size_t)nslab * 2048u + (size_t)(j * per + r) * 1024u + lane * 16u;
+        xp_glds16_asm(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)p * 1024u)));
+    }
+}
+
+// OWNPIX: own blocks = pixel blocks wid + 8*i (i < NO), shared = the workgroup's NSH channel blocks.
+// !OWNPIX: own blocks = channel blocks wid + 8*i, shared = the image's NSH pixel blocks.
+template <int NO, int NSH, int PS, bool OWNPIX>
+__device__ __forceinline__ void xp_pw_direct_body(const xp_args &a, const xp_phase &P, int b, int j, int e_in, int pi) {
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.arena, 0, a.arena_bytes, 0x00020000);
     const uint32_t dimg = a.d_off[P.dbuf] + (uint32_t)b * a.d_img_stride;
-    int rb[3], cb[3], nr = 0;
+    const uint32_t wslice = P.w_off + (uint32_t)(j * P.ncb) * 2048u;  // this workgroup's channel blocks inside a k-step of the weights
+    const uint32_t pix_kstr = (uint32_t)P.nrb * 2048u, w_kstr = (uint32_t)P.nslab * 2048u;
+    const int nown = OWNPIX ? P.nrb : P.ncb;
+    int ob[3], no = 0;
+    uint32_t own_base[3], sh_base[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        rb[i] = wid + 8 * i;                                          // WR == 8, WC == 1
-        nr += rb[i] < P.nrb ? 1 : 0;
-        rb[i] = rb[i] < P.nrb ? rb[i] : 0;
-        cb[i] = i < P.ncb ? i : 0;
+        ob[i] = wid + 8 * i;
+        no += (ob[i] < nown && i < NO) ? 1 : 0;
+        ob[i] = ob[i] < nown ? ob[i] : 0;                             // (a wave without blocks works on block 0; the result is discarded)
+        own_base[i] = (OWNPIX ? dimg : wslice) + (uint32_t)ob[i] * 2048u;
     }
-    const int nc = P.ncb;
-    const int fr = lane & 15, fq = lane >> 4, nl4 = fq * 4;
-    float4 scv[3], bsv[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        const int n = j * P.ncb * 16 + cb[jj] * 16 + nl4;
-        scv[jj] = *reinterpret_cast<const float4 *>(P.scale + n);
-        bsv[jj] = *reinterpret_cast<const float4 *>(P.bias + n);
-    }
-    uint32_t wb[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int s = wid + 8 * t;
-        wb[t] = s < 2 * P.ncb ? P.w_off + (uint32_t)(j * P.ncb * 2 + s) * 1024u : X_OOB;
+        const int s = wid + 8 * t;                                    // piece s of the shared operand's step (block s>>1, hi|lo)
+        sh_base[t] = s < 2 * NSH ? (OWNPIX ? wslice : dimg) + (uint32_t)s * 1024u : X_OOB;
     }
-    floatx4 acc[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) acc[i][jj] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4, nl4 = fq * 4;
     const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) * 16);
-    const uint32_t wk = (uint32_t)P.nslab * 2048u;
-    XP_ISTAMP(a, 4 * pi + 1)
-    switch (nr * 4 + nc) {                                            // wave-uniform; every variant runs the same number of barriers
-    case 4 * 3 + 3: xp_pw_direct_loop<3, 3, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 3 + 2: xp_pw_direct_loop<3, 2, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 3 + 1: xp_pw_direct_loop<3, 1, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 2 + 3: xp_pw_direct_loop<2, 3, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 2 + 2: xp_pw_direct_loop<2, 2, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 2 + 1: xp_pw_direct_loop<2, 1, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 1 + 3: xp_pw_direct_loop<1, 3, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    case 4 * 1 + 2: xp_pw_direct_loop<1, 2, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;
-    default: xp_pw_direct_loop<1, 1, PB>(rs, dimg, P.nks, P.nrb, rb, cb, foff, wid, lane, wb, wk, acc); break;   // (also a wave without row blocks: block 0 again, discarded)
+    floatx4 acc[NO][NSH];
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NSH; ++jj) acc[i][jj] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // BatchNorm scale / bias of this lane's channels: requested first, used last
+    constexpr int NCH = OWNPIX ? NSH : NO;
+    float4 scv[NCH], bsv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int n = j * P.ncb * 16 + (OWNPIX ? c : ob[c]) * 16 + nl4;
+        scv[c] = *reinterpret_cast<const float4 *>(P.scale + n);
+        bsv[c] = *reinterpret_cast<const float4 *>(P.bias + n);
+    }
+    if (OWNPIX && P.resident) {
+        if (P.resident == 1) xp_preload_weights(a, P.w_off, P.nks, P.ncb, P.nslab, j);      // (2: the phase before it has asked for them already)
+        // the BUILTIN wait, not inline asm: hipcc must know the LDS-DMA has landed, or it drains the fragment loads (vmcnt(0)) in front of
+        // the first weight-fragment read of every loop iteration (it did: one full load latency per three steps)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+        __syncthreads();
+        XP_ISTAMP(a, 4 * pi + 1)
+        if (P.nks == 12) xp_pw_resident_loop<NO, NSH, 12>(rs, 12, own_base, pix_kstr, foff, acc, a.dbg);
+        else xp_pw_resident_loop<NO, NSH, 0>(rs, P.nks, own_base, pix_kstr, foff, acc, a.dbg);
+    } else {
+        XP_ISTAMP(a, 4 * pi + 1)
+        xp_pw_direct_loop<NO, NSH, PS, OWNPIX>(rs, P.nks, own_base, OWNPIX ? pix_kstr : w_kstr, sh_base, OWNPIX ? w_kstr : pix_kstr, foff, wid, lane, acc, a.dbg);
     }
     XP_ISTAMP(a, 4 * pi + 2)
-    x_wait_vm<0>();
-    XP_ISTAMP(a, 4 * pi + 3)
-    // ---- epilogue: lane holds channels nl..nl+3 of pixel rb*16 + fr; the y image has its own LDS (nobody reads it during this phase)
+    // the next depthwise phase's parameter slice: requested here, not ahead of the loop (a pending LDS-DMA makes hipcc drain every
+    // load in front of the loop's LDS reads); it lands under the epilogue
+    if (P.nd_par) xp_fetch_par(P.nd_par, P.nd_Cp, P.nd_Gs, j);
+    // ---- epilogue: lane holds channels nl..nl+3 of pixel pb*16 + fr; the y image has its own LDS (nobody reads it during this phase)
     const float up = x_pow2(e_in);
     const uint32_t ypl = xp_ypl(P);
     const int npx = P.H * P.W, W2 = P.W + 2;
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        if (jj >= nc) continue;
-        const int nloc = cb[jj] * 16 + nl4;
-        const float4 sc = scv[jj], bs = bsv[jj];
+    for (int i = 0; i < NO; ++i) {
+        if (i >= no) continue;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int m = rb[i] * 16 + fr;
-            if (i >= nr || m >= npx) continue;
+        for (int jj = 0; jj < NSH; ++jj) {
+            const int cbk = OWNPIX ? jj : ob[i], pbk = OWNPIX ? ob[i] : jj;
+            const int nloc = cbk * 16 + nl4, m = pbk * 16 + fr;
+            if (m >= npx) continue;
+            const float4 sc = scv[OWNPIX ? jj : i], bs = bsv[OWNPIX ? jj : i];
             float4 v;
             v.x = x_actf(__builtin_fmaf(acc[i][jj][0] * up, sc.x, bs.x), P.pslope, P.pcap);
             v.y = x_actf(__builtin_fmaf(acc[i][jj][1] * up, sc.y, bs.y), P.pslope, P.pcap);
@@ -606,8 +751,26 @@ __device__ __forceinline__ void xp_pw_direct(const xp_args &a, const xp_phase &P
             *reinterpret_cast<float4 *>(xsm + ((nloc >> 2) & 1) * ypl + (q * P.Gs + (nloc >> 3)) * 16) = v;
         }
     }
+    XP_ISTAMP(a, 4 * pi + 3)
     if (P.zero_border) xp_zero_border(P);
     __syncthreads();
+}
+// a wave's number of own blocks (wave-uniform: 18 pixel blocks over 8 waves = 3,3,2,2,2,2,2,2) picks its loop; every variant runs the same
+// number of barriers
+template <int NOMAX, int NSH, int PS, bool OWNPIX>
+__device__ __forceinline__ void xp_pw_direct(const xp_args &a, const xp_phase &P, int b, int j, int e_in, int pi) {
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nown = OWNPIX ? P.nrb : P.ncb;
+    int no = 0;
+#pragma unroll
+    for (int i = 0; i < NOMAX; ++i) no += (wid + 8 * i) < nown ? 1 : 0;
+    if constexpr (NOMAX >= 3) {
+        if (no >= 3) return xp_pw_direct_body<3, NSH, PS, OWNPIX>(a, P, b, j, e_in, pi);
+    }
+    if constexpr (NOMAX >= 2) {
+        if (no == 2) return xp_pw_direct_body<2, NSH, PS, OWNPIX>(a, P, b, j, e_in, pi);
+    }
+    return xp_pw_direct_body<1, NSH, PS, OWNPIX>(a, P, b, j, e_in, pi);
 }
 
 __global__ void __launch_bounds__(XP_NT) xp_kernel(const xp_args a) {
@@ -638,22 +801,22 @@ __global__ void __launch_bounds__(XP_NT) xp_kernel(const xp_args a) {
             } else if (P.type == XP_DW) {
                 float wg_max;
                 ed = xp_dw(a, P, b, j, ay, same_xcd, s_max, &wg_max);
-                float *slotp = a.pmax + ((size_t)pi * a.B + b) * a.CW;
-                if (threadIdx.x == 0) __hip_atomic_store(slotp + j, wg_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                arrivals += (uint32_t)a.CW;
+                ++arrivals;
                 XP_STAMP(4 * pi + 1)
-                xp_cluster_barrier(a.cnt + b, arrivals, a.err);
-                md = 0.f;
-                for (int k = 0; k < a.CW; ++k) md = fmaxf(md, __hip_atomic_load(slotp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (arrivals == (uint32_t)a.CW) {                     // first barrier of the image: where does everybody run?
+                md = xp_cluster_barrier(a.gran + (size_t)b * a.CW, a.CW, j, arrivals, wg_max, s_max, a.err);
+                if (arrivals == 1u) {                                 // first barrier of the image: where does everybody run?
                     bool same = true;
                     for (int k = 0; k < a.CW; ++k) same = same && __hip_atomic_load(a.pxcc + (size_t)b * a.CW + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;
                     same_xcd = same && !X_DBG(a, 32);
                 }
             } else if (P.type == XP_PW) {
                 ay = fminf(P.pcap, P.pgain * md + P.poff);
-                if (P.adirect == 1) xp_pw_direct<1>(a, P, b, j, ed, pi);
-                else if (P.adirect == 2) xp_pw_direct<2>(a, P, b, j, ed, pi);
+                // (own blocks per wave, shared blocks, shared pieces per wave, which operand is private) - instantiated for the shapes
+                // x_build_persist accepts; anything else keeps the LDS-ring form below
+                if (P.adirect == 1) xp_pw_direct<3, 3, 1, true>(a, P, b, j, ed, pi);          // <= 24 pixel blocks x 3 channel blocks
+                else if (P.adirect == 2) xp_pw_direct<1, 5, 2, false>(a, P, b, j, ed, pi);    // 5 pixel blocks x <= 8 channel blocks
+                else if (P.adirect == 3) xp_pw_direct<3, 2, 1, true>(a, P, b, j, ed, pi);
+                else if (P.adirect == 4) xp_pw_direct<2, 5, 2, false>(a, P, b, j, ed, pi);    // 5 pixel blocks x <= 16 channel blocks
                 else if (P.ppw == 3) xp_pw<3>(a, P, b, j, ed, pi);
                 else if (P.ppw == 4) xp_pw<4>(a, P, b, j, ed, pi);
                 else if (P.ppw == 5) xp_pw<5>(a, P, b, j, ed, pi);
