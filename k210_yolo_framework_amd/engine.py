@@ -417,8 +417,8 @@ class Pipeline:
     `depth` plans, each with its own outputs / split-K slabs, on `depth` HIP streams (decode scratch is per stream inside the
     library) let the GPU interleave workgroups of different batches; nothing is shared between them but the weight values.
 
-    graph=True (default): a slot's step - (host -> device copy) -> (letterbox) -> yk_run_u8 -> decode + per-class NMS -> results - is
-    captured once as a hipGraph and REPLAYED: one host call per batch instead of ~30 launches.  A captured step is bound to the
+    graph=True (default): a slot's step - (letterbox) -> yk_run_u8 -> decode + per-class NMS -> results - is captured once as a
+    hipGraph and REPLAYED: one host call per batch instead of ~30 launches (the host -> device copy of submit_host goes in front of it).  A captured step is bound to the
     buffers it was captured with: device frames are replayed in place when they live at an address the slot has already captured
     (the slot's own `input(i)` buffer, or up to two caller buffers - a resident ring), and are copied into `input(i)` otherwise.
 
@@ -487,12 +487,16 @@ class Pipeline:
             s.h_offsets.zero_()
 
     # -- the step, as the library calls it is made of (eager, or recorded by capture()) ---------------------------------
+    def _h2d(self, s, B):
+        """The host -> device leg, issued EAGERLY in front of the replay (measured: as a copy node inside the captured step the same
+        6.9 MB took 0.57 ms per batch against 0.46 ms in front of it - bench.py secondary, round 4)."""
+        _check(lib().yk_memcpy_async(C.c_void_p(s.src.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()), s.st),
+               'yk_memcpy_async')
+
     def _issue(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
         L = lib()
         H, W = self.spec.in_hw
         if host:
-            _check(L.yk_memcpy_async(C.c_void_p(s.src.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()), s.st),
-                   'yk_memcpy_async')
             src_ptr = s.src.data_ptr()
         x = src_ptr
         if self.src_hw:
@@ -512,6 +516,8 @@ class Pipeline:
         if max_out > self.max_out:
             raise YkError(f'max_out {max_out} > the pipeline\'s max_out {self.max_out}')
         args = (B, src_ptr, host, use_hw, float(obj), float(iou), int(max_out), bool(want_index))
+        if host:
+            self._h2d(s, B)
         if not self.graph:
             return self._issue(s, *args)
         g = s.graphs.get(args)

@@ -86,7 +86,35 @@ class Batch:
         self.x, self.labels, self.ready, self.n = x, labels, ready, n
 
 
-_PINNED: dict = {}            # (device, what, shape, dtype) -> ring of [pinned tensor, event of its last H2D copy]
+# Pinned host staging buffers, shared by the epochs' pipelines of a process (allocating pinned memory per batch costs more than the
+# batch).  Keyed by CAPACITY BUCKET, not by shape: real VOC lists hold hundreds of image sizes and the count of every size varies from
+# batch to batch - a ring per exact (count, h, w) would pin a new buffer for nearly every batch and never give it back.  A request takes
+# a reshaped view of the prefix of a power-of-two sized byte buffer; the total is capped and the least recently used ring is released.
+_PINNED: "dict" = {}          # (device, what, bucket bytes) -> {'ring': [[pinned uint8 tensor, event of its last H2D copy], ...], 'tick': last use}
+_PINNED_CAP_BYTES = 1 << 30   # upper bound of page-locked staging memory per process
+_pinned_clock = 0
+_pinned_lock = threading.Lock()
+
+
+def _bucket(nbytes: int) -> int:
+    return 1 << max(12, (int(nbytes) - 1).bit_length())
+
+
+def pinned_bytes() -> int:
+    return sum(sl[0].numel() for e in _PINNED.values() for sl in e['ring'])
+
+
+def _evict(keep_key, need: int) -> None:
+    """Release least recently used rings (never `keep_key`) until `need` more bytes fit under the cap."""
+    while _PINNED and pinned_bytes() + need > _PINNED_CAP_BYTES:
+        victims = [k for k in _PINNED if k != keep_key]
+        if not victims:
+            return
+        k = min(victims, key=lambda kk: _PINNED[kk]['tick'])
+        for sl in _PINNED[k]['ring']:
+            if sl[1] is not None:
+                sl[1].synchronize()
+        del _PINNED[k]
 
 
 class InputPipeline:
@@ -119,17 +147,27 @@ class InputPipeline:
         return np.ascontiguousarray(img[..., :3], np.uint8)
 
     def _slot(self, key, shape, dtype):
-        """A pinned host staging buffer from a small ring (allocating pinned memory per batch costs more than the batch)."""
+        """[view of a pinned host staging buffer shaped `shape`, its slot] from a small ring per capacity bucket."""
         import torch
-        ring = _PINNED.setdefault((self.dev.index, key, tuple(shape), dtype), [])     # shared by the epochs' pipelines: pin once
-        nslots = self.q.maxsize + 2                                         # more than the batches that can be outstanding
-        if len(ring) < nslots:
-            ring.append([torch.empty(shape, dtype=dtype).pin_memory(), None])
-            return ring[-1]
-        slot = ring[self._tick % nslots]
+        global _pinned_clock
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        bk = _bucket(nbytes)
+        k = (self.dev.index, key, bk)
+        with _pinned_lock:
+            _pinned_clock += 1
+            e = _PINNED.setdefault(k, {'ring': [], 'tick': 0})
+            e['tick'] = _pinned_clock
+            ring = e['ring']
+            nslots = self.q.maxsize + 2                                     # more than the batches that can be outstanding
+            if len(ring) < nslots:
+                _evict(k, bk)
+                ring.append([torch.empty((bk,), dtype=torch.uint8).pin_memory(), None])
+                slot = ring[-1]
+            else:
+                slot = ring[self._tick % nslots]
         if slot[1] is not None:
             slot[1].synchronize()                                           # its last H2D copy has left the buffer
-        return slot
+        return slot[0][:nbytes].view(dtype).view(tuple(shape)), slot
 
     def _produce(self):
         import torch
@@ -152,19 +190,19 @@ class InputPipeline:
                 labs = self.h.batch_box_to_label(letterbox_boxes_batch(self.h, [im.shape[:2] for im in imgs],
                                                                        [self.items[int(i)][1] for i in rows]))
                 lab_slots = [self._slot(('lab', l), labs[l].shape, torch.float32) for l in range(len(labs))]
-                for sl, lab in zip(lab_slots, labs):
-                    sl[0].numpy()[...] = lab
+                for (view, _), lab in zip(lab_slots, labs):
+                    view.numpy()[...] = lab
                 with torch.cuda.stream(self.stream):
                     frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=self.dev)
                     by_size = {}
                     for k, img in enumerate(imgs):
                         by_size.setdefault(img.shape[:2], []).append(k)
                     for (sh, sw), idx in by_size.items():                   # equal-sized images are letterboxed in one launch
-                        slot = self._slot('img', (len(idx), sh, sw, 3), torch.uint8)
-                        hv = slot[0].numpy()
+                        view, slot = self._slot('img', (len(idx), sh, sw, 3), torch.uint8)
+                        hv = view.numpy()
                         for j, k in enumerate(idx):
                             hv[j] = imgs[k]
-                        src = slot[0].to(self.dev, non_blocking=True)
+                        src = view.to(self.dev, non_blocking=True)
                         slot[1] = torch.cuda.Event()
                         slot[1].record(self.stream)
                         out = engine.letterbox_u8(src, (H, W), stream=self.stream)
@@ -176,19 +214,30 @@ class InputPipeline:
                     engine._check(L.yk_normalise_u8(engine._ptr(frames), n, engine.C.c_size_t(H * W * 3), engine._ptr(x),
                                                     engine._stream(self.stream)), 'yk_normalise_u8')
                     labels = []
-                    for slot in lab_slots:
-                        labels.append(slot[0].to(self.dev, non_blocking=True))
+                    for view, slot in lab_slots:
+                        labels.append(view.to(self.dev, non_blocking=True))
                         slot[1] = torch.cuda.Event()
                         slot[1].record(self.stream)
                     ready = torch.cuda.Event()
                     ready.record(self.stream)
                 self.images += n
                 self.seconds += time.perf_counter() - t0
-                self.q.put(Batch(x, labels, ready, n))
+                if not self._put(Batch(x, labels, ready, n)):
+                    return
         except BaseException as e:                                          # surface worker errors in the consumer
-            self.q.put(e)
+            self._put(e)
             return
-        self.q.put(None)
+        self._put(None)
+
+    def _put(self, item) -> bool:
+        """queue.put that gives up when the consumer has gone away (close() after an early break): never blocks forever."""
+        while not self._stop:
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def __iter__(self):
         import torch
@@ -201,18 +250,41 @@ class InputPipeline:
                 break
             if isinstance(b, BaseException):
                 raise b
-            torch.cuda.current_stream().wait_event(b.ready)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(b.ready)
+            # the tensors were allocated on the producer's side stream and are consumed on this one: tell the caching allocator, or a
+            # block could go back to the producer while kernels queued here still read it
+            b.x.record_stream(cur)
+            for t in b.labels:
+                t.record_stream(cur)
             yield b.x, b.labels
         self._thread.join()
 
     def close(self):
+        """Stop the producer and wait for it: drains the queue until the thread has exited (it may be blocked in put), then the pool."""
         self._stop = True
+        t = self._thread
+        while t is not None and t.is_alive():
+            try:
+                while True:
+                    self.q.get_nowait()
+            except queue.Empty:
+                pass
+            t.join(timeout=0.05)
         try:
             while True:
                 self.q.get_nowait()
         except queue.Empty:
             pass
-        self.pool.shutdown(wait=False)
+        self._thread = None
+        self.pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def producer_images_per_sec(self) -> float:
         """Rate of the producer alone (decode + labels + H2D + GPU letterbox / normalise), not limited by the consumer."""

@@ -126,17 +126,19 @@ def main(args, train_set, class_num, pre_ckpt, model_def, depth_multiplier, is_a
         # tools/utils.py:417-450: each rank decodes only its rows of the global batch, on a thread pool, two batches ahead;
         # letterbox + normalise on the GPU (pipeline.py)
         pipe = InputPipeline(h, h.train_list, batch_size, rank, world, seed=rand_seed, epoch=epoch, shuffle=True, device=local)
-        for x, ys in pipe:
-            out = tr.step(x, ys)
-            seen, run, steps = seen + 1, run + out['loss'], steps + 1
-            if rank == 0 and (seen % 10 == 0 or seen == 1):
-                pr = tr.precision_recall()
-                print(f'epoch {epoch + 1} step {seen}: loss {out["loss"]:.4f} ' +
-                      ' '.join(f'l{i + 1}_p {p:.3f} l{i + 1}_r {r:.3f}' for i, (p, r) in enumerate(pr)), flush=True)
-            if max_steps and steps >= max_steps:
-                break
-        pipe_rate = pipe.producer_images_per_sec()
-        pipe.close()
+        try:                                                                    # an exception in the step must not leave the producer running
+            for x, ys in pipe:
+                out = tr.step(x, ys)
+                seen, run, steps = seen + 1, run + out['loss'], steps + 1
+                if rank == 0 and (seen % 10 == 0 or seen == 1):
+                    pr = tr.precision_recall()
+                    print(f'epoch {epoch + 1} step {seen}: loss {out["loss"]:.4f} ' +
+                          ' '.join(f'l{i + 1}_p {p:.3f} l{i + 1}_r {r:.3f}' for i, (p, r) in enumerate(pr)), flush=True)
+                if max_steps and steps >= max_steps:
+                    break
+            pipe_rate = pipe.producer_images_per_sec()
+        finally:
+            pipe.close()
         val = validate(tr, h, spec, per_rank, rank) if rank == 0 and len(h.test_list) >= per_rank else None
         if rank == 0:
             print(f'epoch {epoch + 1}: {seen} steps, mean loss {run / max(seen, 1):.4f}, ' +

@@ -1,5 +1,5 @@
 """engine.Pipeline as captured hipGraphs (yk_graph_*): a replayed step gives exactly what the eager step gives, holds nothing but
-kernels (plus ONE host-to-device copy on the from-host path), and the from-host path delivers the reference's concatenated detections
+kernels (the host-to-device copy of the from-host path is issued in front of the replay), and the from-host path delivers the reference's concatenated detections
 (keras_inference.py:133-135) to host memory at their live size."""
 import numpy as np
 import pytest
@@ -80,7 +80,7 @@ def test_from_host_ticket_delivers_the_concatenated_detections():
                     assert np.array_equal(idx[off[b]:off[b + 1]], i[b, :c[b]])
         if graph:
             host_graphs = [g for s in pipe.slots for k, g in s.graphs.items() if k[2]]
-            assert host_graphs and all(g.nodes == g.kernel_nodes + 1 for g in host_graphs)   # the H2D copy is the only non-kernel node
+            assert host_graphs and all(g.nodes == g.kernel_nodes for g in host_graphs)       # kernels only: the H2D copy goes in front of the replay
         # frames staged by the caller in the slot's pinned buffer: no host-side copy at all
         i0 = pipe.next_slot()
         pipe.host_input(i0)[:B].copy_(torch.from_numpy(batches[0]))

@@ -55,3 +55,55 @@ def test_worker_errors_reach_the_consumer():
     with pytest.raises(Exception):
         list(pipe)
     pipe.close()
+
+
+def test_pinned_staging_memory_is_bounded_on_many_image_sizes(monkeypatch):
+    """Real VOC lists hold hundreds of image sizes and the count of each size varies per batch: the staging rings are keyed by capacity
+    bucket and capped, so page-locked memory stays bounded - and the batches are still the host generator's."""
+    from k210_yolo_framework_amd import pipeline, training
+    from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS
+    h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [[7, 10], [14, 20]])
+    rng = np.random.default_rng(9)
+    items = []
+    for k in range(96):
+        hw = (int(rng.integers(200, 400)), int(rng.integers(300, 520)))         # (nearly) every image its own size
+        img = rng.integers(0, 256, (*hw, 3), dtype=np.uint8)
+        boxes = np.concatenate([rng.integers(0, 20, (2, 1)).astype(float), rng.uniform(0.2, 0.8, (2, 2)), rng.uniform(0.05, 0.3, (2, 2))], 1)
+        items.append((img, boxes))
+    pipeline._PINNED.clear()
+    monkeypatch.setattr(pipeline, '_PINNED_CAP_BYTES', 24 << 20)
+    order = pipeline.epoch_order(len(items), seed=1, epoch=0, shuffle=True)
+
+    class _Fixed:
+        def permutation(self, n):
+            return order
+    want = list(training.batches(h, items, 8, _Fixed(), shuffle=True))
+    pipe = pipeline.InputPipeline(h, items, 8, 0, 1, seed=1, epoch=0, shuffle=True)
+    peak = 0
+    for (x, ys), (wx, wys) in zip(pipe, want):
+        np.testing.assert_array_equal(x.cpu().numpy(), wx)
+        for gy, wy in zip(ys, wys):
+            np.testing.assert_array_equal(gy.cpu().numpy(), wy)
+        peak = max(peak, pipeline.pinned_bytes())
+    pipe.close()
+    assert 0 < peak <= (24 << 20) + (4 << 20), peak                             # one ring may overshoot by its own newest buffer
+    assert all(pipeline._bucket(n) >= n and pipeline._bucket(n) < 2 * max(n, 4096) for n in (1, 4095, 4096, 4097, 10_000_000))
+
+
+def test_close_after_an_early_break_stops_the_producer():
+    import threading
+    import time
+    from k210_yolo_framework_amd import pipeline
+    from k210_yolo_framework_amd.helper import Helper, VOC_ANCHORS
+    h = Helper(None, 20, VOC_ANCHORS, [[224, 320]], [[7, 10], [14, 20]])
+    rng = np.random.default_rng(2)
+    items = [(rng.integers(0, 256, (240, 320, 3), dtype=np.uint8), np.array([[1, .5, .5, .2, .2]])) for _ in range(64)]
+    before = threading.active_count()
+    pipe = pipeline.InputPipeline(h, items, 4, 0, 1, prefetch=1)
+    for k, _ in enumerate(pipe):
+        if k == 1:
+            break                                                               # the producer is (about to be) blocked in put
+    t0 = time.time()
+    pipe.close()
+    assert time.time() - t0 < 5.0
+    assert pipe._thread is None and threading.active_count() <= before + 1      # (pool threads are joined by shutdown)
