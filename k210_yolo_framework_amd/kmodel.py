@@ -134,6 +134,8 @@ def parse(data: bytes) -> Kmodel:
     if ver != 3:
         raise KmodelError(f'kmodel: version {ver} (only v3, nncase 0.1, is understood)')
     off = 28
+    if nout > 64 or nl > 4096 or off + 8 * (nout + nl) > len(data):
+        raise KmodelError(f'kmodel: header announces {nout} outputs and {nl} layers, the file has {len(data)} bytes')
     outs = [struct.unpack_from('<2I', data, off + 8 * i) for i in range(nout)]
     off += 8 * nout
     hdrs = [struct.unpack_from('<2I', data, off + 8 * i) for i in range(nl)]
@@ -143,6 +145,9 @@ def parse(data: bytes) -> Kmodel:
         if pos + sz > len(data):
             raise KmodelError(f'kmodel: layer {i} runs past the end of the file')
         body = data[pos:pos + sz]
+        need = {KL_K210_CONV: 24, KL_DEQUANTIZE: 24, KL_REQUANTIZE: 272, KL_QUANTIZED_CONCAT: 12, KL_QUANTIZED_RESIZE_NN: 36, KL_K210_UPLOAD: 24}.get(ty)
+        if need is not None and sz < need:
+            raise KmodelError(f'kmodel: layer {i} (type {ty}) has a {sz}-byte body, at least {need} expected')
         if ty == KL_K210_CONV:
             km.layers.append(_parse_conv(i, data, body))
         elif ty == KL_DEQUANTIZE:
@@ -154,6 +159,8 @@ def parse(data: bytes) -> Kmodel:
             km.layers.append(MemLayer(i, ty, dict(flags=fl, src=src, dst=dst, count=cnt, table=np.frombuffer(body, np.uint8, 256, 16).copy())))
         elif ty == KL_QUANTIZED_CONCAT:
             fl, dst, n = struct.unpack_from('<3I', body, 0)
+            if 12 + 8 * n > sz:
+                raise KmodelError(f'kmodel: layer {i}: concat of {n} inputs does not fit its {sz}-byte body')
             ins = [struct.unpack_from('<2I', body, 12 + 8 * k) for k in range(n)]
             km.layers.append(MemLayer(i, ty, dict(flags=fl, dst=dst, inputs=[(int(a), int(s)) for a, s in ins])))
         elif ty == KL_QUANTIZED_RESIZE_NN:
@@ -170,6 +177,14 @@ def parse(data: bytes) -> Kmodel:
 
 def _parse_conv(index: int, data: bytes, body: bytes) -> ConvLayer:
     fl, mmout, lo, wo, bo, ao = struct.unpack_from('<6I', body, 0)
+    # every offset comes out of an untrusted file: check each region against the file before touching it
+    n = len(data)
+    if lo + 96 > n:
+        raise KmodelError(f'kmodel: conv layer {index}: register block at {lo} runs past the end of the file ({n} bytes)')
+    if not (wo <= bo <= n):
+        raise KmodelError(f'kmodel: conv layer {index}: weight / BatchNorm offsets {wo}, {bo} are out of order or past the end of the file')
+    if ao + 128 + 16 > n:
+        raise KmodelError(f'kmodel: conv layer {index}: activation table at {ao} runs past the end of the file')
     r = struct.unpack_from('<12Q', data, lo)
     depthwise = bool(_bits(r[0], 3, 1))
     src, dst = _bits(r[1], 0, 15), _bits(r[1], 32, 15)
@@ -185,6 +200,8 @@ def _parse_conv(index: int, data: bytes, body: bytes) -> ConvLayer:
     # (kernel_load_cfg.para_size is the bytes of ONE parameter load; big layers are loaded in several passes of o_ch_num_coef channels)
     if bo - wo < nw:
         raise KmodelError(f'kmodel: conv layer {index}: {bo - wo} weight bytes in the file, {nw} expected (16-bit weights are not supported)')
+    if bo + 8 * oc > n:
+        raise KmodelError(f'kmodel: conv layer {index}: BatchNorm table of {oc} channels at {bo} runs past the end of the file')
     w = np.frombuffer(data, np.uint8, nw, wo).reshape(oc, 1 if depthwise else ic, ks * ks).copy()
     bn = np.frombuffer(data, '<u8', oc, bo)
     bn_mul = np.array([_bits(int(v), 0, 24, True) for v in bn], np.int64)
@@ -257,6 +274,20 @@ def to_float_weights(km: Kmodel) -> Tuple[Dict[str, np.ndarray], dict]:
     convs = km.convs
     if len(convs) != len(YOLO_MOBILEV1_ORDER):
         raise KmodelError(f'kmodel: {len(convs)} KPU conv layers; the yolo_mobilev1 graph has {len(YOLO_MOBILEV1_ORDER)}')
+    # every conv against the layer of yolo_mobilev1-0.75 it is mapped onto (kernel size, depthwise, channels, no KPU pooling): a kmodel
+    # of another network with the same NUMBER of convs must not be dequantised into this one's names
+    from . import netspec as ns
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    want = {l.name: l for l in spec.layers}
+    for name, c in zip(YOLO_MOBILEV1_ORDER, convs):
+        kh, _, ci, co = want[name].kernel_shape
+        dw = want[name].kind == 'dwconv'
+        exp = (kh, dw, ci, ci if dw else co)
+        got = (c.ksize, bool(c.depthwise), c.in_ch, c.out_ch)
+        if got != exp:
+            raise KmodelError(f'kmodel: conv {c.index} is (k, depthwise, in, out) = {got}; yolo_mobilev1-0.75 layer {name} is {exp}')
+        if c.pool_type not in (0, 5):          # 5 = keep the top-left sample of every 2x2 window: how the KPU runs a stride-2 conv
+            raise KmodelError(f'kmodel: conv {c.index} ({name}) uses KPU pooling type {c.pool_type}; the graph has no pooling layers')
     mem = [l for l in km.layers if isinstance(l, MemLayer)]
     deq = {l.fields['src']: l.fields for l in mem if l.type == KL_DEQUANTIZE}
     req = [l.fields for l in mem if l.type == KL_REQUANTIZE]

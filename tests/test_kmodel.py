@@ -116,3 +116,32 @@ def test_dequantised_network_follows_the_integer_pipeline_and_finds_dog_bicycle_
     assert set(found) == {'dog', 'bicycle', 'car'}, found
     dog = found['dog']
     assert 30 < dog[0] < 80 and 120 < dog[2] < 180 and dog[3] > 180          # lower left of the picture
+
+
+def test_malformed_files_raise_kmodel_errors_not_struct_errors():
+    """The parser trusts no offset of the file: truncations and wild offsets are KmodelErrors with the layer named."""
+    import struct
+    from k210_yolo_framework_amd import kmodel
+    data = (GOLD / 'yolo.kmodel').read_bytes() if 'GOLD' in globals() else open('tests/golden/yolo.kmodel', 'rb').read()
+    km = kmodel.parse(data)
+    for cut in (10, 27, 60, 400, len(data) // 2, len(data) - 5):
+        with pytest.raises(kmodel.KmodelError):
+            kmodel.to_float_weights(kmodel.parse(data[:cut]))
+    # wild offsets inside the first conv layer's body: register block, weights, BatchNorm, activation table
+    ver, fl, arch, nl, ms, mm, nout = struct.unpack_from('<7I', data, 0)
+    pos = 28 + 8 * nout + 8 * nl
+    hdrs = [struct.unpack_from('<2I', data, 28 + 8 * nout + 8 * i) for i in range(nl)]
+    for ty, sz in hdrs:
+        if ty == kmodel.KL_K210_CONV:
+            break
+        pos += sz
+    for field in (2, 3, 4, 5):                       # layer_offset, weights_offset, bn_offset, act_offset of kpu_model_conv_layer_argument_t
+        bad = bytearray(data)
+        struct.pack_into('<I', bad, pos + 4 * field, 0xFFFFFF00)
+        with pytest.raises(kmodel.KmodelError):
+            kmodel.parse(bytes(bad))
+    # a network with the same number of convs but another shape must not be dequantised into yolo_mobilev1's names
+    c = km.convs[3]
+    c.out_ch += 8
+    with pytest.raises(kmodel.KmodelError, match='yolo_mobilev1'):
+        kmodel.to_float_weights(km)
