@@ -70,14 +70,18 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
         decode_ref.decode_batch([o.reshape(n, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors, spec.in_hw, spec.in_hw, 0.7, 0.5)
 
     def chain(fwd, budget):
-        t_total, n = 0.0, 0
+        t_total, t_fwd, n = 0.0, 0.0, 0
         while t_total < budget and n < 512:
             frames = rng.integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8)
             t0 = time.perf_counter()
-            decode(fwd(oracle.normalise_u8(frames)), B)
-            t_total += time.perf_counter() - t0
+            outs = fwd(oracle.normalise_u8(frames))
+            t1 = time.perf_counter()
+            decode(outs, B)
+            t2 = time.perf_counter()
+            t_total += t2 - t0
+            t_fwd += t1 - t0
             n += B
-        return n / t_total, n, t_total
+        return n / t_total, n, t_total, n / t_fwd
     res, used, probes = {}, {}, {}
     # (1) the C port: its OpenMP team is probed on 8 frames (a team of every logical CPU spin-waits at each loop barrier)
     pr = {}
@@ -115,6 +119,8 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
                       f'C port on {used["port"]} threads: {res["port"][0]:.1f} images/s over {res["port"][1]} frames ({res["port"][2]:.1f} s); '
                       f'torch-CPU on {used["graph"]} threads: {res["graph"][0]:.1f} images/s over {res["graph"][1]} frames ({res["graph"][2]:.1f} s)',
             'port_images_per_sec': round(res['port'][0], 1), 'torch_cpu_images_per_sec': round(res['graph'][0], 1),
+            # the decode of this leg is decode_ref.py (numpy, one thread; random weights give ~350 boxes per image): without it
+            'conv_stack_only_images_per_sec': {'port': round(res['port'][3], 1), 'torch_cpu': round(res['graph'][3], 1)},
             'thread_probe_images_per_sec': probes}
 
 

@@ -1166,7 +1166,7 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
     auto pw_ok = [&](const xlaunch &l) {
         const xg_args &g = l.c;
         return l.kind == XK_CONV && g.ks == 1 && g.stride == 1 && !g.s1.p && !g.up0 && !g.res.p && g.splitk == 1 && g.out && l.in_tid >= 0 &&
-               (g.N % (8 * CW)) == 0 && (g.s0.G % CW) == 0 && (g.s0.G % 4) == 0;
+               (g.N % (16 * CW)) == 0 && (g.s0.G % CW) == 0 && (g.s0.G % 4) == 0;      // whole 16-channel blocks per member
     };
     auto dw_ok = [&](const xlaunch &l) { return l.kind == XK_DW && (l.d.in.G % CW) == 0 && (l.d.in.G % 4) == 0; };
     auto y_fits = [&](int H, int W, int Gs) { return (unsigned)(2 * (H + 2) * (W + 2) * Gs * 16) <= ring_cap; };
@@ -1900,7 +1900,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         l.name = nm;
         p->L.push_back(l);
     }
-    if (yk_env_flag("YK_PERSIST", true) && !yk_dev_env("YK_X_NOPERSIST")) {
+    if (yk_env_flag("YK_PERSIST", true) && fuse_blocks && !yk_dev_env("YK_X_NOPERSIST")) {      // YK_FUSE_DWPW=0: one launch per layer
         if ((rc = x_build_persist(p, max_batch))) return fail(rc);
     }
     for (int t : p->outputs)

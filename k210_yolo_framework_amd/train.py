@@ -405,25 +405,42 @@ class Trainer:
         self._graph.replay()
         return self._gres
 
-    def step(self, x_nhwc, y_true: Sequence["torch.Tensor"]) -> Dict[str, float]:
-        """model.fit's inner step (keras_train.py:94).  Returns python floats (one device->host sync)."""
-        torch = self.torch
-        r = self._loss_and_grads_replayed(x_nhwc, y_true)
-        if self.world > 1:
-            import torch.distributed as dist
-            from .shard import allreduce_gradients
-            # data-term gradients already carry 1/global_batch, so SUM over ranks is the global-batch gradient;
-            # the regulariser's gradient is identical on every rank and is added once, after the reduction
+    def exchange(self, reduce=None) -> None:
+        """The data-parallel exchange of one step: SUM the flat gradient bucket over the ranks, then add the regulariser's gradient
+        (identical on every rank) once.  `reduce(flat_grad)` replaces the all-reduce — tests drive several replicas of one process
+        through exactly this code with it."""
+        import torch.distributed as dist
+        from .shard import allreduce_gradients
+        # data-term gradients already carry 1/global_batch, so SUM over ranks is the global-batch gradient
+        if reduce is not None:
+            reduce(self.G)
+        else:
+            if not dist.is_initialized():
+                raise engine.YkError(f'Trainer(world_size={self.world}) needs an initialised torch.distributed process group')
             allreduce_gradients(self.G, dist, self.pg)
-            self.regulariser(add_grad=True)
+        self.regulariser(add_grad=True)
+
+    def apply_update(self) -> None:
+        """keras Adam(lr, decay) on the flat buffers (keras_train.py:73-76); one launch."""
         self._ck(self.L.yk_adam_f32(C.c_longlong(self.n_params), engine._ptr(self.P), engine._ptr(self.G), engine._ptr(self.m),
                                     engine._ptr(self.v), C.c_float(self.lr), C.c_float(self.decay), C.c_longlong(self.iterations),
                                     C.c_float(0.9), C.c_float(0.999), C.c_float(1e-7), C.c_float(1.0), self._s()), 'yk_adam_f32')
         self.iterations += 1
+
+    def step(self, x_nhwc, y_true: Sequence["torch.Tensor"], reduce=None, reduce_scalar=None) -> Dict[str, float]:
+        """model.fit's inner step (keras_train.py:94).  Returns python floats (one device->host sync)."""
+        torch = self.torch
+        r = self._loss_and_grads_replayed(x_nhwc, y_true)
+        if self.world > 1:
+            self.exchange(reduce)
+        self.apply_update()
         data = torch.stack([p[0] for p in r['layers']]).sum()
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.pg)
+            if reduce_scalar is not None:
+                reduce_scalar(data)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(data, op=dist.ReduceOp.SUM, group=self.pg)
         vals = torch.cat([data.view(1), r['reg'].view(1)]).cpu().numpy()
         return dict(loss=float(vals[0] + vals[1]), data_loss=float(vals[0]), reg_loss=float(vals[1]))
 

@@ -146,7 +146,7 @@ def test_capture_refuses_a_cold_stream():
         engine.decode_py(cfg, plan.outputs(), 2, None, 0.7, 0.5)
     st.synchronize()
     g = engine.capture(C.c_void_p(st.cuda_stream), issue)
-    assert g.nodes == g.kernel_nodes > 20
+    assert g.nodes == g.kernel_nodes > 10
     g.launch(C.c_void_p(st.cuda_stream))
     st.synchronize()
     g.close()

@@ -95,7 +95,8 @@ def test_four_plans_in_flight_assemble_their_clusters():
 def test_other_networks_keep_their_plain_launches_or_persist_consistently():
     """yolo_mobilev2 / tiny_yolo / Darknet have no dw -> 1x1 chain of the supported form at these sizes, or a short one: whatever the plan
     chooses, outputs equal the YK_PERSIST=0 plan's."""
-    for name, shape, alpha in (('yolo_mobilev2', (224, 320, 3), 1.0), ('tiny_yolo', (416, 416, 3), 1.0), ('yolo_mobilev1', (96, 64, 3), 0.5)):
+    for name, shape, alpha in (('yolo_mobilev2', (224, 320, 3), 1.0), ('tiny_yolo', (416, 416, 3), 1.0), ('yolo_mobilev1', (96, 64, 3), 0.5),
+                               ('yolo_mobilev1', (64, 96, 3), 0.75), ('yolo_mobilev1', (128, 160, 3), 1.0)):
         spec = ns.NETWORKS[name](shape, 3, 20, alpha=alpha)
         w = spec.init_weights(seed=1)
         f = np.random.default_rng(0).integers(0, 256, (2, *shape), dtype=np.uint8)
