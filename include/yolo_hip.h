@@ -140,6 +140,15 @@ int yk_plan_create(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t
  *                       the tolerance (scores drift ~2e-4 mean / 2e-3..5e-3 max from the fp32 Keras path). */
 #define YK_PRECISION_F16 0
 #define YK_PRECISION_F16X2 1
+/* OR-ed into `precision` (f16x2 only; ignored by f16): how the late backbone and the detection heads are launched.
+ *   YK_SCHEDULE_THROUGHPUT (default)  one launch per layer: kernels of several batches in flight on several streams overlap best
+ *                                      (bench.py `value`: four batches in flight);
+ *   YK_SCHEDULE_LATENCY               two launches of per-image workgroup clusters (csrc/yk_xpersist.h, csrc/yk_xheads.h): every CU
+ *                                      is held for their duration, the time of ONE batch is shortest (669 -> 542 us of kernels at 32 images).
+ * Same arithmetic; results differ at the 2^-22 rounding level (summation order).  YK_PERSIST / YK_HEADS = 0|1 in the environment override. */
+#define YK_SCHEDULE_THROUGHPUT 0x000
+#define YK_SCHEDULE_LATENCY 0x100
+#define YK_SCHEDULE_MASK 0xf00
 int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors,
                       const float *blob, size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch,
                       int device, int precision);

@@ -140,7 +140,7 @@ int yk_launch_add(const yk_half *a, const yk_half *b, yk_half *out, size_t n8, h
 // ---- "f16x2" precision mode (yk_exact.hip): fp32 activations, compensated fp16 MFMA operands ----------------------
 struct yk_xplan;
 int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors, const float *blob,
-                    size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch);
+                    size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch, int latency_schedule);
 void yk_xplan_destroy(yk_xplan *p);
 int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream_t st, hipEvent_t *ev);
 int yk_xplan_output(yk_xplan *p, int idx, float **d_ptr, size_t *bytes, int *h, int *w, int *c);

@@ -193,8 +193,10 @@ extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops,
         }
         p->outputs.push_back(outputs[i]);
     }
+    const int schedule = precision & YK_SCHEDULE_MASK;
+    precision &= ~YK_SCHEDULE_MASK;
     if (precision == YK_PRECISION_F16X2) {
-        rc = yk_xplan_create(&p->x, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch);
+        rc = yk_xplan_create(&p->x, ops, n_ops, tensors, n_tensors, blob, blob_len, outputs, n_outputs, max_batch, schedule == YK_SCHEDULE_LATENCY);
         if (rc) return fail(rc);
         *out = p;
         return YK_OK;

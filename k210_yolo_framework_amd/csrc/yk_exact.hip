@@ -715,6 +715,7 @@ void xdw_geometry(xdw_args &d, int max_batch) {
 
 #include "yk_xblock.h"
 #include "yk_xpersist.h"
+#include "yk_xheads.h"
 
 // =====================================================================================================================
 // stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once.
@@ -927,7 +928,7 @@ float x_h2f(uint16_t u) {
     return (float)h;
 }
 
-enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK, XK_PERSIST };
+enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK, XK_PERSIST, XK_HEADS };
 enum { XT_REAL = 0, XT_UP = 1, XT_CAT = 2 };
 // tile configurations of xg_kernel
 enum { XC_64x64 = 0, XC_64x128, XC_128x64, XC_128x128, XC_NUM };
@@ -958,6 +959,8 @@ struct xlaunch {
     unsigned lds = 0;
     int in_tid = -1, out_tid = -1;     // tensors of a plain depthwise / 1x1 conv launch (chain detection of the persistent stage)
     xp_args pa;                        // XK_PERSIST
+    xh_args ha;                        // XK_HEADS
+    unsigned h_lds = 0;
     int p_cw = 0;
     std::string name;
     double flops = 0, bytes = 0;
@@ -1331,7 +1334,7 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
     a.CW = CW;
     a.arena = (const uint8_t *)ar;
     a.arena_bytes = (uint32_t)total;
-    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - (size_t)max_batch * CW * 2));
+    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - 2 * (size_t)max_batch * CW * 2));
     if ((rc = x_alloc(p, &px, sizeof(uint32_t) * (size_t)max_batch * CW))) return rc;
     a.pxcc = (uint32_t *)px;
     a.err = p->d_err;
@@ -1347,8 +1350,157 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
     return YK_OK;
 }
 
+
+// ---- the detection heads as one launch (yk_xheads.h) ---------------------------------------------------------------------------
+// Takes the plan's trailing run of stride-1 'same' convs (3x3 -> network-output 1x1 pairs and the 1x1 in front of the UpSampling2D)
+// when every one of them fits a kernel instantiation; otherwise the plain launches stay.  Depends on the network and the image size only.
+static int x_build_heads_from(yk_xplan *p, int max_batch, int first, bool *built);
+static int x_build_heads(yk_xplan *p, int max_batch) {
+    const int n = (int)p->L.size();
+    int first = n;
+    while (first > 0 && p->L[first - 1].kind == XK_CONV) --first;
+    // the longest suffix of the trailing convs that fits (the convs in front of it, e.g. the backbone's last pointwise conv, stay launches)
+    for (; n - first >= 2; ++first) {
+        bool built = false;
+        const int rc = x_build_heads_from(p, max_batch, first, &built);
+        if (rc || built) return rc;
+    }
+    return YK_OK;
+}
+static int x_build_heads_from(yk_xplan *p, int max_batch, int first, bool *built) {
+    const int n = (int)p->L.size();
+    auto conv_ok = [&](const xg_args &g) {
+        return g.stride == 1 && !g.res.p && g.Ho == g.Hi && g.Wo == g.Wi &&
+               ((g.ks == 1 && g.pad_t == 0 && g.pad_l == 0) || (g.ks == 3 && g.pad_t == 1 && g.pad_l == 1));
+    };
+    struct item {
+        xh_phase q;
+        int out_tid;
+        std::string nm;
+        double flops, bytes;
+    };
+    std::vector<item> ph;
+    unsigned lds_main = 0;
+    for (int k = first; k < n; ++k) {
+        const xlaunch &l = p->L[k];
+        const xg_args &g = l.c;
+        if (!conv_ok(g) || g.out32 || !g.out || (g.N % 16) != 0) return YK_OK;
+        item it;
+        xh_phase &q = it.q;
+        memset(&q, 0, sizeof(q));
+        auto src = [&](const xview &v, int up, int nch) {
+            xh_src s;
+            s.p = v.p; s.eexp = v.eexp; s.amax = v.amax; s.bytes = v.bytes; s.G = v.G; s.H = v.H; s.W = v.W; s.up = up; s.nchunk = nch;
+            return s;
+        };
+        q.s0 = src(g.s0, g.up0, g.nc0);
+        if (g.s1.p) q.s1 = src(g.s1, 0, g.nc1);
+        if (g.up0 && (g.s0.H * 2 != g.Hi || g.s0.W * 2 != g.Wi)) return YK_OK;
+        q.H = g.Ho; q.W = g.Wo; q.W2 = g.Wo + 2; q.PP = (g.Ho + 2) * q.W2; q.taps = g.taps;
+        q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_w2 = yk_make_fastdiv((uint32_t)q.W2);
+        q.nrb = (g.Ho * g.Wo + 15) / 16; q.ncb = g.N / 16; q.nchunk = g.nc0 + g.nc1;
+        if (q.PP > 384) return YK_OK;
+        if (q.taps == 9 && q.nrb <= 5 && q.ncb <= 12 && q.nchunk <= 24 && !g.s1.p) { q.variant = 1; q.WR = 1; q.WC = 4; q.WK = 2; }
+        else if (q.taps == 9 && q.nrb <= 18 && q.ncb <= 8 && q.nchunk <= 16) { q.variant = 0; q.WR = 2; q.WC = 4; q.WK = 1; }
+        else if (q.taps == 1 && q.nrb <= 5 && q.ncb <= 8 && q.nchunk <= 24 && !g.s1.p) { q.variant = 2; q.WR = 1; q.WC = 4; q.WK = 2; }
+        else return YK_OK;
+        q.plane = (uint32_t)q.PP * 64u; q.img = 2u * q.plane;
+        const int nslots = std::min(XH_NCH, (q.nchunk + XH_CW - 1) / XH_CW);
+        lds_main = std::max(lds_main, (unsigned)nslots * q.img);
+        q.w = g.w; q.w_bytes = g.w_bytes; q.nslab = g.nslab; q.scale = g.scale; q.bias = g.bias;
+        q.slope = g.slope; q.cap = g.cap; q.gain0 = g.gain0; q.gain1 = g.gain1; q.off = g.off;
+        q.nslot = XH_CW;
+        if (q.WK == 2) lds_main = std::max(lds_main, (unsigned)(q.nrb * q.ncb * 1024));
+        it.out_tid = l.out_tid;
+        it.nm = l.name.substr(2, l.name.find('[') == std::string::npos ? std::string::npos : l.name.find('[') - 2);
+        it.flops = l.flops; it.bytes = l.bytes;
+        const bool tail = k + 1 < n && p->L[k + 1].c.out32 && p->L[k + 1].c.ks == 1 && conv_ok(p->L[k + 1].c) && !p->L[k + 1].c.s1.p && !p->L[k + 1].c.up0 &&
+                          p->L[k + 1].c.s0.p == g.out && l.out_tid >= 0 && p->T[l.out_tid].uses == 1;
+        if (tail) {
+            const xlaunch &lt = p->L[k + 1];
+            const xg_args &t = lt.c;
+            q.tw = t.w; q.tw_bytes = t.w_bytes; q.t_nslab = t.nslab; q.t_N = t.N; q.t_ncb = (t.N + 15) / 16; q.t_nks = t.nc0;
+            q.t_scale = t.scale; q.t_bias = t.bias; q.t_slope = t.slope; q.t_cap = t.cap; q.out32 = t.out32;
+            if (q.t_nks * 32 < q.ncb * 16 || q.t_ncb > q.t_nslab || q.t_nks > 6) return YK_OK;
+            lds_main = std::max(lds_main, (unsigned)(48 * (q.ncb * 16 + 4) * 4 + 64));
+            it.nm += "+" + lt.name.substr(2, lt.name.find('[') == std::string::npos ? std::string::npos : lt.name.find('[') - 2);
+            it.flops += lt.flops; it.bytes += lt.bytes;
+            ++k;
+        } else {
+            q.out = g.out; q.out_bytes = (uint32_t)((size_t)max_batch * g.Ho * g.Wo * g.outG * 32); q.outG = g.outG; q.eexp_out = g.eexp_out; q.amax_out = g.amax_out;
+        }
+        ph.push_back(it);
+    }
+    if (ph.empty() || (int)ph.size() > XH_MAXPH) return YK_OK;
+    if (lds_main + 256 > 156 * 1024) return YK_OK;
+    // a stored output that a later phase reads goes first: its consumer then has another phase's barrier between them
+    std::stable_sort(ph.begin(), ph.end(), [&](const item &a, const item &b) {
+        auto feeds = [&](const item &x) {
+            if (!x.q.out) return 0;
+            for (const item &y : ph)
+                if (y.q.s0.p == x.q.out || y.q.s1.p == x.q.out) return 1;
+            return 0;
+        };
+        return feeds(a) > feeds(b);
+    });
+    uint32_t poff = 0;
+    for (size_t i = 0; i < ph.size(); ++i) {
+        xh_phase &q = ph[i].q;
+        q.part_off = poff;
+        poff += (uint32_t)q.nslot * (uint32_t)q.nrb * (uint32_t)q.ncb * 1024u;
+        // every source must be complete: produced by an earlier kernel, or by a phase with a barrier between it and this one
+        for (size_t k = 0; k < ph.size(); ++k) {
+            const bool reads = ph[k].q.out && (q.s0.p == ph[k].q.out || q.s1.p == ph[k].q.out);
+            if (!reads) continue;
+            if (k >= i) return YK_OK;                                  // (cannot happen in a feed-forward plan)
+            if (k + 1 == i) q.pre_barrier = 1;
+        }
+    }
+    if (ph.size() == 1) ph[0].q.pre_barrier = 1;                       // the partial-sum region is reused by the cluster's next image
+    const size_t total = (size_t)32 * poff;
+    if (total + 65536 >= X_OOB) return YK_OK;
+    std::vector<xh_phase> dev;
+    for (auto &it : ph) dev.push_back(it.q);
+    void *dpart = nullptr, *dph = nullptr, *px = nullptr;
+    int rc;
+    if ((rc = x_alloc(p, &dpart, total + 65536))) return rc;
+    if ((rc = x_upload(p, &dph, dev.data(), dev.size() * sizeof(xh_phase)))) return rc;
+    if ((rc = x_alloc(p, &px, sizeof(uint32_t) * (size_t)max_batch * XH_CW))) return rc;
+    xlaunch l;
+    l.kind = XK_HEADS;
+    xh_args &a = l.ha;
+    memset(&a, 0, sizeof(a));
+    a.ph = (const xh_phase *)dph;
+    a.n_phase = (int)dev.size();
+    a.CW = XH_CW;
+    a.part = (uint8_t *)dpart;
+    a.part_stride = poff;
+    a.part_bytes = (uint32_t)total;
+    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - (size_t)max_batch * XH_CW * 2));
+    a.pxcc = (uint32_t *)px;
+    a.err = p->d_err;
+    a.lds_misc = (lds_main + 63u) & ~63u;
+    l.h_lds = a.lds_misc + 256;
+    std::string nm = "x:heads[";
+    int nbar = 0;
+    for (size_t i = 0; i < ph.size(); ++i) {
+        nm += (i ? " | " : "") + ph[i].nm;
+        l.flops += ph[i].flops;
+        l.bytes += ph[i].bytes;
+        nbar += 1 + ph[i].q.pre_barrier;
+        if (ph[i].q.tw && ph[i].out_tid >= 0) p->T[ph[i].out_tid].d = nullptr;        // never leaves the cluster
+    }
+    char tl[96];
+    snprintf(tl, sizeof tl, ";K split over %d wg/image,%d cluster barriers]", XH_CW, nbar);
+    l.name = nm + tl;
+    p->L.erase(p->L.begin() + first, p->L.end());
+    p->L.push_back(l);
+    *built = true;
+    return YK_OK;
+}
+
 int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors, const float *blob,
-                    size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch) {
+                    size_t blob_len, const int32_t *outputs, int n_outputs, int max_batch, int latency_schedule) {
     yk_xplan *p = new yk_xplan();
     p->max_batch = max_batch;
     int rc = YK_OK;
@@ -1477,7 +1629,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    p->zero_words = (size_t)n_tensors * max_batch * XS + (size_t)max_batch * 8 * 2;   // + the persistent stage's barrier granules
+    p->zero_words = (size_t)n_tensors * max_batch * XS + 2 * (size_t)max_batch * 8 * 2;   // + the barrier granules of the persistent stage and of the heads
     if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
     if ((rc = x_alloc(p, (void **)&p->d_err, 256))) return fail(rc);
     if ((rc = x_alloc(p, (void **)&p->d_eexp, sizeof(int) * (size_t)n_tensors * max_batch))) return fail(rc);
@@ -1900,8 +2052,14 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         l.name = nm;
         p->L.push_back(l);
     }
-    if (yk_env_flag("YK_PERSIST", true) && fuse_blocks && !yk_dev_env("YK_X_NOPERSIST")) {      // YK_FUSE_DWPW=0: one launch per layer
+    // The two cluster launches hold every CU for their whole duration: the shortest time of ONE batch (one-batch latency 669 -> 542 us of
+    // kernels), but with several batches in flight on several streams the launch-per-layer form overlaps better (78 k vs 68 k images/s, four in
+    // flight; profiles/r04_schedules.txt).  YK_SCHEDULE_LATENCY selects them; YK_PERSIST / YK_HEADS = 0|1 override either way.
+    if (yk_env_flag("YK_PERSIST", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOPERSIST")) {      // YK_FUSE_DWPW=0: one launch per layer
         if ((rc = x_build_persist(p, max_batch))) return fail(rc);
+    }
+    if (yk_env_flag("YK_HEADS", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOHEADS")) {
+        if ((rc = x_build_heads(p, max_batch))) return fail(rc);
     }
     for (int t : p->outputs)
         if (!p->T[t].d32 || !p->T[t].net_out) {
@@ -1982,6 +2140,19 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             if (const char *e = yk_dev_env("YK_XP_DBG")) pa.dbg = atoi(e);
             hipLaunchKernelGGL(xp_kernel, dim3((unsigned)(pa.n_cluster * l.p_cw)), dim3(XP_NT), XP_NS * 8 * 6 * 1024 + XP_MISC, st, pa);
         } break;
+        case XK_HEADS: {
+            xh_args ha = l.ha;
+            ha.B = batch;
+            ha.n_cluster = 8 * std::min(4, (batch + 7) / 8);
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                once = true;
+            }
+            ha.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
+            if (const char *e = yk_dev_env("YK_XH_DBG")) ha.dbg = atoi(e);
+            hipLaunchKernelGGL(xh_kernel, dim3((unsigned)(ha.n_cluster * XH_CW)), dim3(XH_NT), l.h_lds, st, ha);
+        } break;
         case XK_POOL: {
             xpool_args q = l.p;
             q.B = batch;
@@ -2042,7 +2213,7 @@ int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t d
 
 // dev instrumentation: arm phase timestamps for launch `li` (a fused block), run once, copy out [n_wg][16] ticks (100 MHz)
 int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipStream_t st, long long *h_out, int max_wg) {
-    if (li < 0 || li >= (int)p->L.size() || (p->L[li].kind != XK_BLOCK && p->L[li].kind != XK_PERSIST)) return YK_ERR_ARG;
+    if (li < 0 || li >= (int)p->L.size() || (p->L[li].kind != XK_BLOCK && p->L[li].kind != XK_PERSIST && p->L[li].kind != XK_HEADS)) return YK_ERR_ARG;
     const size_t cap = 65536;
     if (!p->d_dbg) {
         int rc = x_alloc(p, (void **)&p->d_dbg, sizeof(long long) * 16 * cap);

@@ -19,6 +19,7 @@ from . import netspec as ns
 LIB_PATH = Path(os.environ.get('YK_LIB_PATH') or Path(__file__).resolve().parent / 'csrc' / 'libyolo_hip.so')
 YK_MAX_LAYERS, YK_MAX_ANCHORS = 4, 8
 PRECISIONS = {'f16': 0, 'f16x2': 1}          # YK_PRECISION_F16 / YK_PRECISION_F16X2
+SCHEDULES = {'throughput': 0x000, 'latency': 0x100}      # YK_SCHEDULE_* (include/yolo_hip.h): per-layer launches | per-image cluster launches
 _lib: Optional[C.CDLL] = None
 
 f32p = C.POINTER(C.c_float)
@@ -119,15 +120,22 @@ class _DevView:
 class Plan:
     """kpu_load_kmodel analogue (main.c:274): a compiled, device-resident network."""
 
-    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None, precision: str = 'f16x2'):
+    def __init__(self, spec: ns.NetSpec, weights, max_batch: int = 32, device: Optional[int] = None, precision: str = 'f16x2',
+                 schedule: str = 'latency'):
         """precision: 'f16x2' (default; activations stored as fp16 pairs hi + lo, compensated fp16 MFMA operands: the mode that meets
         BASELINE.json's 1e-3 / exact-index tolerance) or 'f16' (fp16 activations, about twice as fast, 5e-3 worst case on the
-        scores); see include/yolo_hip.h YK_PRECISION_*."""
+        scores); see include/yolo_hip.h YK_PRECISION_*.
+        schedule (f16x2): 'latency' - the late backbone and the heads as two launches of per-image workgroup clusters, the shortest time
+        for ONE batch (a Plan on its own runs one batch at a time, hence the default here) - or 'throughput' - one launch per layer,
+        which overlaps better when several plans run on several streams (Pipeline picks it for depth >= 2); YK_SCHEDULE_*."""
         import torch
         require_gpu()
         if precision not in PRECISIONS:
             raise YkError(f'precision {precision!r}: expected one of {sorted(PRECISIONS)}')
+        if schedule not in SCHEDULES:
+            raise YkError(f'schedule {schedule!r}: expected one of {sorted(SCHEDULES)}')
         self.precision = precision
+        self.schedule = schedule
         self.spec = spec
         self.max_batch = int(max_batch)
         self.device = torch.cuda.current_device() if device is None else int(device)
@@ -141,7 +149,7 @@ class Plan:
         _check(L.yk_plan_create_ex(C.byref(self._h), self._ops.ctypes.data_as(i32p), C.c_int(len(ops)),
                                    self._tens.ctypes.data_as(i32p), C.c_int(len(tens)), blob.ctypes.data_as(f32p),
                                    C.c_size_t(blob.size), outs.ctypes.data_as(i32p), C.c_int(len(outs)),
-                                   C.c_int(self.max_batch), C.c_int(self.device), C.c_int(PRECISIONS[precision])), 'yk_plan_create_ex')
+                                   C.c_int(self.max_batch), C.c_int(self.device), C.c_int(PRECISIONS[precision] | SCHEDULES[schedule])), 'yk_plan_create_ex')
         self._out_views = None
 
     def close(self):
@@ -427,14 +435,18 @@ class Pipeline:
     delivers the detections to host memory at their live size; see Ticket."""
 
     def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None,
-                 precision: str = 'f16x2', graph: bool = True, src_hw: Optional[Tuple[int, int]] = None, max_out: int = 30):
+                 precision: str = 'f16x2', graph: bool = True, src_hw: Optional[Tuple[int, int]] = None, max_out: int = 30,
+                 schedule: str = 'auto'):
+        """schedule: 'auto' = 'latency' for depth 1 (one batch at a time: the cluster launches finish it soonest), 'throughput' for
+        depth >= 2 (batches in flight on several streams: the launch-per-layer form overlaps better); see Plan."""
         import torch
         require_gpu()
         self.depth = max(1, int(depth))
+        self.schedule = ('latency' if self.depth == 1 else 'throughput') if schedule == 'auto' else schedule
         self.spec, self.max_batch, self.graph = spec, int(max_batch), bool(graph)
         self.src_hw = None if src_hw is None else (int(src_hw[0]), int(src_hw[1]))     # frames of this size are letterboxed on the GPU
         self.max_out = int(max_out)
-        self.plans = [Plan(spec, weights, max_batch=max_batch, device=device, precision=precision) for _ in range(self.depth)]
+        self.plans = [Plan(spec, weights, max_batch=max_batch, device=device, precision=precision, schedule=self.schedule) for _ in range(self.depth)]
         self.outs = [p.outputs() for p in self.plans]
         dev = torch.device(f'cuda:{self.plans[0].device}')
         cur = torch.cuda.current_stream()

@@ -271,7 +271,7 @@ def test_pipeline_three_batches_in_flight_equal_one_at_a_time(precision):
     B, N = 16, 9
     g = torch.Generator(device='cuda').manual_seed(5)
     frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g) for _ in range(N)]
-    plan = engine.Plan(spec, w, max_batch=B, precision=precision)
+    plan = engine.Plan(spec, w, max_batch=B, precision=precision, schedule='throughput')      # what a Pipeline of depth 3 builds
     cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
     ref = []
     for f in frames:

@@ -98,7 +98,7 @@ def test_letterboxing_pipeline_equals_letterbox_then_run():
     B = 4
     g = torch.Generator(device='cuda').manual_seed(2)
     cam = torch.randint(0, 256, (B, 240, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
-    plan = engine.Plan(spec, w, max_batch=B)
+    plan = engine.Plan(spec, w, max_batch=B, schedule='throughput')                  # what a Pipeline of depth 2 builds
     cfg = engine.make_decode_cfg(VOC_ANCHORS, 20, spec.in_hw, spec.out_hw())
     plan.run_u8(engine.letterbox_u8(cam, (224, 320)))
     d0, c0 = engine.decode_py(cfg, plan.outputs(), B, None, 0.7, 0.5)

@@ -70,7 +70,7 @@ def test_four_plans_in_flight_assemble_their_clusters():
     B = 32
     g = torch.Generator(device='cuda').manual_seed(3)
     frames = [torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g) for _ in range(4)]
-    one = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=1)
+    one = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=1, schedule='latency')
     want = []
     for f in frames:
         d, c, _ = one.submit(f)
@@ -78,7 +78,7 @@ def test_four_plans_in_flight_assemble_their_clusters():
         want.append((d.cpu().numpy().copy(), c.cpu().numpy().copy()))
     one.plans[0].check()
     one.close()
-    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=4)
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=4, schedule='latency')     # (depth >= 2 would pick the per-layer launches)
     for rnd in range(25):
         got = [pipe.submit(f) for f in frames]
         pipe.wait()

@@ -6,9 +6,10 @@
 #   asan   libyolo_hip_asan.so needs the ASan runtime preloaded into python.  The HIP runtime of some images aborts during device
 #          discovery with that runtime present (no report, `Fatal Python error: Aborted` inside torch.cuda.is_available); the script
 #          probes that first and says so instead of failing the whole run.
+# -s: a sanitizer report goes to stderr and the process aborts - pytest's capture would swallow it.
 # Python itself is not instrumented: leak detection is off (the interpreter's own allocations would drown the report).
 cd "$(dirname "$0")/.." || exit 1
-TESTS=${@:-tests/test_gpu_graph.py tests/test_gpu_region.py tests/test_gpu_decode.py tests/test_gpu_persist.py tests/test_abi.py -m gpu -q -x}
+TESTS=${@:-tests/test_gpu_graph.py tests/test_gpu_region.py tests/test_gpu_decode.py tests/test_gpu_persist.py tests/test_abi.py -m gpu -q -x -s}
 CS=$PWD/k210_yolo_framework_amd/csrc
 rc=0
 echo "== ubsan"
