@@ -424,9 +424,14 @@ def main():
         # ---- roofline of the dominant kernel, HIP events on the launch stream.  Algorithmic bytes are SURVEY 8(d)'s (every layer's
         # input + output once at fp16), whatever the mode stores: the f16x2 plan reports its bytes at 4 B per element, so its
         # launches are halved to that basis (the mode really moves twice as much; `frac_of_mode_bytes` prices that)
-        plan = single.plans[0]
+        # The plan that produces `value` (S batches in flight: engine.Pipeline picks the launch-per-layer schedule for depth >= 2); the plan of
+        # the one-batch measurement (depth 1: the two cluster launches, YK_SCHEDULE_LATENCY) is listed beside it in config.latency_schedule.
+        plan = head.plans[0]
         ms = plan.profile(frames, iters=20)
         launches = plan.launches()
+        lat_plan = single.plans[0]
+        lat_ms = lat_plan.profile(frames, iters=20) if lat_plan is not plan else ms
+        lat_launches = lat_plan.launches()
         basis = 0.5 if args.precision == 'f16x2' else 1.0
         dom = int(np.argmax(ms))
         name, flops_img, bytes_img = launches[dom]
@@ -446,7 +451,7 @@ def main():
                     'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None}
         # HBM bytes of that launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
         # tools/one_step.py + tools/profiles_post.py; counters cannot be collected from inside this process)
-        tags = ('r03_x2', 'r02') if args.precision == 'f16x2' else ('r03', 'r02', 'r01')
+        tags = ('r04_x2', 'r03_x2', 'r02') if args.precision == 'f16x2' else ('r03', 'r02', 'r01')
         for tag in tags:
             try:
                 prof = json.load(open(ROOT / 'profiles' / f'{tag}_hbm_traffic.json'))
@@ -461,7 +466,8 @@ def main():
         fam, t_roof_sum = {}, 0.0
         for i, (nm, fl, by) in enumerate(launches):
             t_roof = max(by * B * basis / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_PEAK_TFLOPS * 1e12)) * 1e6
-            key = ('stem' if 'stem' in nm else 'u8_max' if 'u8_max' in nm else 'dw+pw block' if ('dw3x3' in nm and 'conv1x1' in nm) else
+            key = ('late backbone (cluster launch)' if nm.startswith('x:persist') else 'heads (cluster launch)' if nm.startswith('x:heads') else
+                   'stem' if 'stem' in nm else 'u8_max' if 'u8_max' in nm else 'dw+pw block' if ('dw3x3' in nm and 'conv1x1' in nm) else
                    'depthwise' if 'dw3x3' in nm else 'conv3x3' if 'conv3x3' in nm else 'split-K finish' if 'splitk_reduce' in nm else 'conv1x1')
             f = fam.setdefault(key, [0.0, 0.0, 0])
             f[0] += float(ms[i]) * 1e3
@@ -494,6 +500,12 @@ def main():
                                    '(independent batches on separate HIP streams, one plan each)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
                        'launch_mode': 'graph' if use_graph else 'eager', 'graph_nodes_per_step': graph_nodes,
+                       'schedule': getattr(head.pipe, 'schedule', None),
+                       'latency_schedule': {'what': 'the plan of one_batch_in_flight_*: engine.Pipeline(depth=1) -> YK_SCHEDULE_LATENCY (late backbone and heads as '
+                                                    'two launches of per-image workgroup clusters)',
+                                            'schedule': getattr(single.pipe, 'schedule', None), 'launches_per_step': len(lat_launches) + 3,
+                                            'sum_kernels_us': round(float(lat_ms.sum()) * 1e3, 1),
+                                            'per_kernel_us': {f'{i}:{lat_launches[i][0][:72]}': round(float(lat_ms[i]) * 1e3, 2) for i in range(len(lat_ms))}},
                        'host_us_per_step': round(host_us, 1),
                        'from_host_host_us_per_step': None if fh_host_us is None else round(fh_host_us, 1), 'batches_in_flight': S, 'precision': args.precision,
                        'tolerance_carried': ('BASELINE north_star: identical detection sets, scores / coords within 1e-3 max '

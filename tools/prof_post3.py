@@ -1,6 +1,7 @@
 """gpurun_out/prof3/ (rocprofv3 CSVs of tools/one_step.py: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE) -> profiles/<tag>_*.
 
     python tools/prof_post3.py r03_x2
+    python tools/prof_post3.py r04_x2 prof4/throughput launch_names_throughput.json        (round 4: one directory per launch schedule)
 
 A step of the plan is found in the kernel stream by its first kernel (u8_max); launches that issue two kernels (split-K conv + finish)
 are folded; the hipMemsetAsync of the f16x2 plan (a fill kernel) is listed on its own."""
@@ -11,9 +12,9 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'gpurun_out', 'prof3')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03_x2'
-meta = json.load(open(os.path.join(root, 'gpurun_out', 'launch_names.json')))
+src = os.path.join(root, 'gpurun_out', sys.argv[2] if len(sys.argv) > 2 else 'prof3')
+meta = json.load(open(os.path.join(root, 'gpurun_out', sys.argv[3] if len(sys.argv) > 3 else 'launch_names.json')))
 L, kpl, alg = meta['launches'], meta['kernels_per_launch'], meta['alg_bytes_per_image']
 basis = 0.5 if meta.get('precision') == 'f16x2' else 1.0      # SURVEY 8(d) counts fp16 bytes; the f16x2 plan reports 4 B per element
 
@@ -54,7 +55,7 @@ for cnt, sub in (('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')):
     per = [fold([float(r['Counter_Value']) for r in run]) for run in rr]
     traffic[cnt] = [sum(p[i] for p in per) / len(per) * 1024 * (2 if cnt == 'FETCH_SIZE' else 1) for i in range(len(L))]
 with open(os.path.join(root, 'profiles', f'{tag}_kernel_trace_per_launch.csv'), 'w', newline='') as fh:
-    fh.write(f'# rocprofv3 --kernel-trace --stats on tools/one_step.py ({meta.get("precision")} plan, B=32, one batch in flight): average duration per '
+    fh.write(f'# rocprofv3 --kernel-trace --stats on tools/one_step.py ({meta.get("precision")} plan, {meta.get("schedule", "per-layer")} schedule, B=32, one batch in flight): average duration per '
              f'launch of the step over {len(dur)} steps (split-K conv + its finishing pass folded); HBM bytes from separate --pmc FETCH_SIZE / '
              'WRITE_SIZE passes (FETCH x2 per MI355X_MICROARCH.md); algorithmic bytes = SURVEY 8(d) basis (fp16 in + out)\n')
     wr = csv.writer(fh)
