@@ -1099,6 +1099,10 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                         best = score;
                         *tm_out = tm; *tn_out = tn; *lds_out = lds;
                         g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p; g.db = db;
+                        // converting a stored patch to fp32 once instead of in every tap: measured slower (49.8 vs 45.3 us, 35.3 vs 32.8 us on the
+                        // two stride-1 blocks: the extra barrier and LDS pass cost more than the 60 conversions per item they save); the
+                        // fused stem writes its patch as fp32 directly (84 -> 78 us)
+                        g.prepass = (s == 1 && yk_dev_env("YK_XB_PREPASS")) ? 1 : 0;
                         g.tiles_x = (g.Wo + TW - 1) / TW;
                         g.tiles_y = (g.Ho + TH - 1) / TH;
                     }

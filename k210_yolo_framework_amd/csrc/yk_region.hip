@@ -420,7 +420,13 @@ extern "C" void region_layer_run(region_layer_t *rl, obj_info_t *obj_info) {
     }
 }
 
-static inline uint32_t to_u32(float v) { return (uint32_t)(int64_t)v; }
+// (uint32_t) of a float as the reference's x86-64 build computes it (cvttss2si to 64 bits, then truncation): NaN and values outside the
+// int64 range give the "integer indefinite" 0x8000000000000000, i.e. 0 after truncation.  Spelled out: the plain cast is undefined
+// behaviour in C for those inputs (found by the UBSan build on a box of garbage coordinates, tools/run_asan.sh).
+static inline uint32_t to_u32(float v) {
+    if (!(v >= -9223372036854775808.0f && v < 9223372036854775808.0f)) return 0u;
+    return (uint32_t)(int64_t)v;
+}
 
 extern "C" void region_layer_draw_boxes(region_layer_t *rl, callback_draw_box callback) {
     const uint32_t image_width = rl->image_width, image_height = rl->image_height;

@@ -42,6 +42,7 @@ struct xb_args {
     // geometry, fixed at plan creation
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
     int db;                            // 1: two stages of (patch, parameters, weight tile), DMA(k+1) requested at the start of step k
+    int prepass;                       // stride-1 block on a stored tensor: the patch is converted to fp32 ONCE, in place, before the taps
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw, fd_nk;
     // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
     // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
@@ -150,18 +151,17 @@ __device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp
         for (int nf = 0; nf < 2; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[nf], xh, acc[nf], 0, 0, 0);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-            half4 hi, lo;
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float u = __builtin_fmaf(acc[nf][k], scv[nf][k], bsv[nf][k]);
                 v[k] = inside ? fminf(fmaxf(u, u * a.st_slope), cap) : 0.f;
             }
-            x_split4(v, hi, lo);
+            // the patch of a fused stem is fp32: [position][4 groups][channels 0-3] in the first plane, [..][channels 4-7] in the second (what
+            // the depthwise taps multiply; round 3 stored (hi | lo) here and every tap converted them back, 72 VALU operations per item)
             if (valid) {
-                const int n = nf * 16 + fq * 4, at = (pos * 4 + (n >> 3)) * 16 + (n & 7) * 2;
-                *reinterpret_cast<half4 *>(HI + at) = hi;
-                *reinterpret_cast<half4 *>(LO + at) = lo;
+                const int n = nf * 16 + fq * 4, at = (pos * 4 + (n >> 3)) * 16;
+                *reinterpret_cast<u32x4 *>(((n & 4) ? LO : HI) + at) = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             }
         }
     }
@@ -394,6 +394,24 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
         const unsigned char *PARB_ = HI + a.n16p * 32;
         const float up = sf[0], dmid = sf[1];
+        const bool f32patch = STEM || a.prepass;
+        if (!STEM && a.prepass) {
+            // stride 1: a patch element feeds nine taps.  (hi, lo) -> fp32 once, in place (channels 0-3 over the hi plane's 16 bytes,
+            // 4-7 over the lo plane's), instead of in every tap: 8 conversions per element here for 72 per item there
+            for (int e = tid; e < a.n16p; e += 256) {
+                const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + e * 16), l = *reinterpret_cast<const u32x4 *>(LO + e * 16);
+                u32x4 x0, x1;
+                x0[0] = __float_as_uint(x_mix_sum_lo(h[0], l[0])); x0[1] = __float_as_uint(x_mix_sum_hi(h[0], l[0]));
+                x0[2] = __float_as_uint(x_mix_sum_lo(h[1], l[1])); x0[3] = __float_as_uint(x_mix_sum_hi(h[1], l[1]));
+                x1[0] = __float_as_uint(x_mix_sum_lo(h[2], l[2])); x1[1] = __float_as_uint(x_mix_sum_hi(h[2], l[2]));
+                x1[2] = __float_as_uint(x_mix_sum_lo(h[3], l[3])); x1[3] = __float_as_uint(x_mix_sum_hi(h[3], l[3]));
+                *reinterpret_cast<u32x4 *>(const_cast<unsigned char *>(HI) + e * 16) = x0;
+                *reinterpret_cast<u32x4 *>(const_cast<unsigned char *>(LO) + e * 16) = x1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         // ---- depthwise: item = (pixel p, group q of this step)
         if (!X_DBG(a, 2))
             for (int it = tid; it < BM * 4; it += 256) {
@@ -413,10 +431,17 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                         const u32x4 w0 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8) * 4), w1 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8 + 4) * 4);
                         const float2v w2[4] = {{__uint_as_float(w0[0]), __uint_as_float(w0[1])}, {__uint_as_float(w0[2]), __uint_as_float(w0[3])},
                                                {__uint_as_float(w1[0]), __uint_as_float(w1[1])}, {__uint_as_float(w1[2]), __uint_as_float(w1[3])}};
+                        if (f32patch) {                               // (h, l) are the fp32 planes: channels 0-3 | 4-7
+                            d2[0] = __builtin_elementwise_fma(float2v{__uint_as_float(h[0]), __uint_as_float(h[1])}, w2[0], d2[0]);
+                            d2[1] = __builtin_elementwise_fma(float2v{__uint_as_float(h[2]), __uint_as_float(h[3])}, w2[1], d2[1]);
+                            d2[2] = __builtin_elementwise_fma(float2v{__uint_as_float(l[0]), __uint_as_float(l[1])}, w2[2], d2[2]);
+                            d2[3] = __builtin_elementwise_fma(float2v{__uint_as_float(l[2]), __uint_as_float(l[3])}, w2[3], d2[3]);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
-                            d2[j] = __builtin_elementwise_fma(x2, w2[j], d2[j]);
+                            for (int j = 0; j < 4; ++j) {
+                                const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
+                                d2[j] = __builtin_elementwise_fma(x2, w2[j], d2[j]);
+                            }
                         }
                     }
                     const float d[8] = {d2[0].x, d2[0].y, d2[1].x, d2[1].y, d2[2].x, d2[2].y, d2[3].x, d2[3].y};
