@@ -398,6 +398,17 @@ def main():
     single = Harness(1, args.precision, letterbox=args.letterbox, from_host=args.from_host, graph=use_graph)
     el1, _ = single.measure(min(args.steps, 100), 5)
     single_ms = el1 / min(args.steps, 100) * 1e3
+    # per-launch times of both plans while they are alive (rank 0), then both harnesses go: with them alive the from-host harness below
+    # would be streams 6-9 of this process, more than the GPU_MAX_HW_QUEUES = 8 hardware queues - its streams then share queues and the
+    # number drops by 10 % (measured: 66.5 k with the two harnesses alive, 72-76 k without)
+    prof = None
+    if rank == 0:
+        p_head, p_lat = head.plans[0], single.plans[0]
+        ms_head = p_head.profile(frames, iters=20)
+        prof = (ms_head, p_head.launches(), p_lat.profile(frames, iters=20) if p_lat is not p_head else ms_head, p_lat.launches(),
+                getattr(head.pipe, 'schedule', None), getattr(single.pipe, 'schedule', None))
+    head.close()
+    single.close()
     # SURVEY 8(d) "end to end" with the PCIe legs: the same step fed from pinned host memory (H2D copy in front of the captured step), detections
     # delivered to pinned host memory; every rank takes part (8(e): host feeding is where the N-GPU curve is expected to bend)
     value_from_host, fh_host_us = None, None
@@ -426,12 +437,7 @@ def main():
         # launches are halved to that basis (the mode really moves twice as much; `frac_of_mode_bytes` prices that)
         # The plan that produces `value` (S batches in flight: engine.Pipeline picks the launch-per-layer schedule for depth >= 2); the plan of
         # the one-batch measurement (depth 1: the two cluster launches, YK_SCHEDULE_LATENCY) is listed beside it in config.latency_schedule.
-        plan = head.plans[0]
-        ms = plan.profile(frames, iters=20)
-        launches = plan.launches()
-        lat_plan = single.plans[0]
-        lat_ms = lat_plan.profile(frames, iters=20) if lat_plan is not plan else ms
-        lat_launches = lat_plan.launches()
+        ms, launches, lat_ms, lat_launches, sched_head, sched_lat = prof
         basis = 0.5 if args.precision == 'f16x2' else 1.0
         dom = int(np.argmax(ms))
         name, flops_img, bytes_img = launches[dom]
@@ -500,10 +506,10 @@ def main():
                                    '(independent batches on separate HIP streams, one plan each)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
                        'launch_mode': 'graph' if use_graph else 'eager', 'graph_nodes_per_step': graph_nodes,
-                       'schedule': getattr(head.pipe, 'schedule', None),
+                       'schedule': sched_head,
                        'latency_schedule': {'what': 'the plan of one_batch_in_flight_*: engine.Pipeline(depth=1) -> YK_SCHEDULE_LATENCY (late backbone and heads as '
                                                     'two launches of per-image workgroup clusters)',
-                                            'schedule': getattr(single.pipe, 'schedule', None), 'launches_per_step': len(lat_launches) + 3,
+                                            'schedule': sched_lat, 'launches_per_step': len(lat_launches) + 3,
                                             'sum_kernels_us': round(float(lat_ms.sum()) * 1e3, 1),
                                             'per_kernel_us': {f'{i}:{lat_launches[i][0][:72]}': round(float(lat_ms[i]) * 1e3, 2) for i in range(len(lat_ms))}},
                        'host_us_per_step': round(host_us, 1),
@@ -522,9 +528,6 @@ def main():
                        'parallelism': f'image-sharded x{world}, no collective'},
             'roofline': roof,
         }
-    head.close()
-    single.close()
-
     def rate(S_, prec, lb, fh, steps=60, graph=None):
         hs = Harness(S_, prec, letterbox=lb, from_host=fh, graph=use_graph if graph is None else graph)
         el, _ = hs.measure(steps, 30, min_s=0.25, max_regions=16)
