@@ -2141,6 +2141,7 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
                 once = true;
             }
             pa.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
+            pa.write_through = yk_env_flag("YK_CLUSTER_WT", false) ? 1 : 0;
             if (const char *e = yk_dev_env("YK_XP_DBG")) pa.dbg = atoi(e);
             hipLaunchKernelGGL(xp_kernel, dim3((unsigned)(pa.n_cluster * l.p_cw)), dim3(XP_NT), XP_NS * 8 * 6 * 1024 + XP_MISC, st, pa);
         } break;
@@ -2154,6 +2155,7 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
                 once = true;
             }
             ha.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
+            ha.write_through = yk_env_flag("YK_CLUSTER_WT", false) ? 1 : 0;
             if (const char *e = yk_dev_env("YK_XH_DBG")) ha.dbg = atoi(e);
             hipLaunchKernelGGL(xh_kernel, dim3((unsigned)(ha.n_cluster * XH_CW)), dim3(XH_NT), l.h_lds, st, ha);
         } break;

@@ -73,6 +73,7 @@ struct xh_args {
     uint32_t *err;
     uint32_t lds_misc;                 // offset of the scalars behind the largest phase's images
     long long *stamps;
+    int write_through;                 // 1: never trust the placement check - every exchange goes write-through + L1-bypassing (YK_CLUSTER_WT=1; tests)
     int dbg;
 };
 
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(XH_NT) xh_kernel(const xh_args a) {
             if (pi == 0) {                                            // the first barrier is behind us: where does everybody run?
                 bool same = true;
                 for (int k = 0; k < a.CW; ++k) same = same && __hip_atomic_load(a.pxcc + (size_t)b * a.CW + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;
-                same_xcd = same && !X_DBG(a, 32);
+                same_xcd = same && !a.write_through && !X_DBG(a, 32);
             }
             __syncthreads();                                          // the tail conv's LDS tile before the next phase's images
         }

@@ -77,6 +77,7 @@ struct xp_args {
     uint32_t *pxcc;                    // [max_batch][CW] XCD id of every member + 1
     uint32_t *err;                     // sticky: a cluster barrier timed out
     long long *stamps;                 // developer builds: [workgroup][4 * XP_MAXPH + 4] wall_clock64 ticks (100 MHz), or null
+    int write_through;                 // 1: never trust the placement check - every exchange goes write-through + L1-bypassing (YK_CLUSTER_WT=1; tests)
     int dbg;                           // developer builds: knock-out bits (1 no MFMA, 2 no operand DMA, 4 no D stores, 8 plain D stores, 16 no dw taps)
 };
 
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(XP_NT) xp_kernel(const xp_args a) {
                 if (arrivals == 1u) {                                 // first barrier of the image: where does everybody run?
                     bool same = true;
                     for (int k = 0; k < a.CW; ++k) same = same && __hip_atomic_load(a.pxcc + (size_t)b * a.CW + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;
-                    same_xcd = same && !X_DBG(a, 32);
+                    same_xcd = same && !a.write_through && !X_DBG(a, 32);
                 }
             } else if (P.type == XP_PW) {
                 ay = fminf(P.pcap, P.pgain * md + P.poff);

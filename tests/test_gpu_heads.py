@@ -110,3 +110,23 @@ def test_schedules_select_the_launch_form_and_agree():
     assert any(n[0].startswith('x:heads') for n in p1.plans[0].launches()) and not any(n[0].startswith('x:heads') for n in p3.plans[0].launches())
     p1.close()
     p3.close()
+
+
+def test_write_through_exchange_gives_the_same_bits():
+    """The cluster launches verify their placement (all members of an image on one XCD -> plain stores, the data stays in that L2) and fall
+    back to write-through stores + L1-bypassing loads otherwise.  On a healthy box the fallback never runs; YK_CLUSTER_WT=1 forces it:
+    same arithmetic, so the outputs must be bit-identical (and the run must not report an unassembled cluster)."""
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=4)
+    f = np.random.default_rng(7).integers(0, 256, (11, 224, 320, 3), dtype=np.uint8)
+    a, names = _outs(spec, w, f, True)
+    assert any(n.startswith('x:persist') for n in names) and any(n.startswith('x:heads') for n in names)
+    os.environ['YK_CLUSTER_WT'] = '1'
+    try:
+        b, _ = _outs(spec, w, f, True)
+        c, _ = _outs(spec, w, f, True)
+    finally:
+        os.environ.pop('YK_CLUSTER_WT', None)
+    for x, y, z in zip(a, b, c):
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(y, z)
