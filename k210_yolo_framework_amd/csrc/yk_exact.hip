@@ -942,6 +942,7 @@ struct xtens {
     int h = 0, w = 0, c = 0, cp = 0, kind = XT_REAL, src0 = -1, src1 = -1;
     bool net_out = false, is_input = false;
     uint8_t *d = nullptr;              // split tensor
+    bool f32 = false;                  // ... stored as fp32 planes instead of (hi | lo): only a fused block's depthwise conv reads it
     float *d32 = nullptr;              // network output
     int uses = 0;
 };
@@ -2056,6 +2057,23 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         l.name = nm;
         p->L.push_back(l);
     }
+    // A fused block's output that only ANOTHER fused block's depthwise conv reads is stored as fp32 (yk_xblock.h: no split in the producer,
+    // no conversions in the consumer's nine taps)
+    if (!yk_dev_env("YK_XB_NOF32"))
+        for (size_t i = 0; i < p->L.size(); ++i) {
+            if (p->L[i].kind != XK_BLOCK || !p->L[i].b.out) continue;
+            int tid = -1;
+            for (size_t t = 0; t < p->T.size(); ++t)
+                if (p->T[t].d == p->L[i].b.out) tid = (int)t;
+            if (tid < 0 || p->T[tid].uses != 1) continue;
+            for (size_t j = i + 1; j < p->L.size(); ++j)
+                if (p->L[j].kind == XK_BLOCK && !p->L[j].b.stem && p->L[j].b.in.p == p->L[i].b.out) {
+                    p->L[i].b.dst_f32 = 1;
+                    p->L[j].b.src_f32 = 1;
+                    p->T[tid].f32 = true;
+                    break;
+                }
+        }
     // The two cluster launches hold every CU for their whole duration: the shortest time of ONE batch (one-batch latency 669 -> 542 us of
     // kernels), but with several batches in flight on several streams the launch-per-layer form overlaps better (78 k vs 68 k images/s, four in
     // flight; profiles/r04_schedules.txt).  YK_SCHEDULE_LATENCY selects them; YK_PERSIST / YK_HEADS = 0|1 override either way.
@@ -2211,6 +2229,11 @@ int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t d
         for (size_t q = 0; q < hw; ++q) {
             const uint16_t *src = hbuf.data() + ((size_t)b * hw + q) * G * 16;
             float *dst = h_dst + ((size_t)b * hw + q) * t.c;
+            if (t.f32) {                                                  // fp32 planes: the group's 32 bytes are eight floats
+                const float *f = reinterpret_cast<const float *>(src);
+                for (int c = 0; c < t.c; ++c) dst[c] = ldexpf(f[c], ee[b]);
+                continue;
+            }
             for (int c = 0; c < t.c; ++c)
                 dst[c] = ldexpf(x_h2f(src[(c >> 3) * 16 + (c & 7)]) + x_h2f(src[(c >> 3) * 16 + 8 + (c & 7)]), ee[b]);
         }

@@ -43,6 +43,9 @@ struct xb_args {
     int TH, TW, PH, PW, tiles_x, tiles_y, n16, n16p;
     int db;                            // 1: two stages of (patch, parameters, weight tile), DMA(k+1) requested at the start of step k
     int prepass;                       // stride-1 block on a stored tensor: the patch is converted to fp32 ONCE, in place, before the taps
+    // A tensor whose only consumer is the depthwise conv of another fused block is stored as FP32 ([pixel][group][ch 0-3 | ch 4-7], the same
+    // 32 bytes per group as (hi | lo), exponent 0): its producer skips the split, its consumer's taps skip 72 conversions per item
+    int src_f32, dst_f32;
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw, fd_nk;
     // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
     // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             bout += x_amax_wave(a.res.amax, (int)b);
             rup = x_pow2(a.res.eexp[b]);
         }
-        const int em = x_exp_of(__float_as_uint(bmid)), eo = x_exp_of(__float_as_uint(bout));
+        const int em = x_exp_of(__float_as_uint(bmid)), eo = a.dst_f32 ? 0 : x_exp_of(__float_as_uint(bout));
         if (lane == 0) {
             sf[0] = x_pow2(STEM ? a.st_e : a.in.eexp[b]);
             sf[1] = x_pow2(-em);
@@ -394,8 +397,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
         const unsigned char *PARB_ = HI + a.n16p * 32;
         const float up = sf[0], dmid = sf[1];
-        const bool f32patch = STEM || a.prepass;
-        if (!STEM && a.prepass) {
+        const bool f32patch = STEM || a.prepass || a.src_f32;
+        if (!STEM && a.prepass && !a.src_f32) {
             // stride 1: a patch element feeds nine taps.  (hi, lo) -> fp32 once, in place (channels 0-3 over the hi plane's 16 bytes,
             // 4-7 over the lo plane's), instead of in every tap: 8 conversions per element here for 72 per item there
             for (int e = tid; e < a.n16p; e += 256) {
@@ -545,17 +548,22 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * rup;
                 }
-                half4 hi, lo;
-                float vd[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 4; ++k)
                     if (mok) rmax = fmaxf(rmax, fabsf(v[k]));
-                    vd[k] = v[k] * dout;
+                if (a.dst_f32) {                                      // fp32 planes of the group: channels 0-3 | 4-7 (exponent 0: no scaling, no split)
+                    *reinterpret_cast<u32x4 *>(Cs + (p - i0 * 16) * C::CPITCH + (nl >> 3) * 32 + ((nl >> 2) & 1) * 16) =
+                        u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                } else {
+                    half4 hi, lo;
+                    float vd[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) vd[k] = v[k] * dout;
+                    x_split4(vd, hi, lo);
+                    unsigned char *d = Cs + (p - i0 * 16) * C::CPITCH + (nl >> 3) * 32 + (nl & 7) * 2;
+                    *reinterpret_cast<half4 *>(d) = hi;
+                    *reinterpret_cast<half4 *>(d + 16) = lo;
                 }
-                x_split4(vd, hi, lo);
-                unsigned char *d = Cs + (p - i0 * 16) * C::CPITCH + (nl >> 3) * 32 + (nl & 7) * 2;
-                *reinterpret_cast<half4 *>(d) = hi;
-                *reinterpret_cast<half4 *>(d + 16) = lo;
             }
         }
         if (i0 == 0) { XB_STAMP(8) }
