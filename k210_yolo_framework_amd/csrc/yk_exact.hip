@@ -1054,10 +1054,13 @@ int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hi
     yk_set_error("f16x2: no fused block kernel <%d,%d>", tm, tn);
     return YK_ERR_ARG;
 }
-unsigned xb_lds(int tm, int tn, int n16p, int db) {
+// the weight tile holds the 16-channel blocks that exist: N = 96 in a 128-wide tile needs 12 KB, not 16 - which is what lets a FOURTH
+// workgroup of the 96 -> 96 block onto a CU (36.8 KB each instead of 40.8)
+int xb_bt_bytes(int tn, int N) { return std::min(64 * tn, (N + 15) / 16 * 16) * 128; }
+unsigned xb_lds(int tm, int tn, int n16p, int db, int N) {
     const int bm = 16 * tm, bn = 64 * tn;
     const int ipp = (tn >= 3 && tm >= 2) ? (tm + 1) / 2 : tm;
-    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + bn * 128) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
+    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + xb_bt_bytes(tn, N)) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
     return (unsigned)(std::max(ring, ct) + 64);
 }
 // Tile geometry of a fused block.  Measured on K2 at B=32 (tools/xbsweep.py: every (TM, TN, tile width, stages) per block): the launch
@@ -1090,7 +1093,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                 if (n16p > 1536) continue;
                 for (int db = 0; db <= 1; ++db) {
                     if (force_db >= 0 ? db != force_db : db != 0) continue;
-                    const unsigned lds = xb_lds(tm, tn, n16p, db);
+                    const unsigned lds = xb_lds(tm, tn, n16p, db, g.N);
                     if (lds > 160 * 1024 || (!forced && lds > 53 * 1024 + 512)) continue;
                     const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
                     const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
@@ -1100,6 +1103,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                         best = score;
                         *tm_out = tm; *tn_out = tn; *lds_out = lds;
                         g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p; g.db = db;
+                        g.bt_bytes = xb_bt_bytes(tn, g.N); g.lds_bytes = (int)lds;
                         // converting a stored patch to fp32 once instead of in every tap: measured slower (49.8 vs 45.3 us, 35.3 vs 32.8 us on the
                         // two stride-1 blocks: the extra barrier and LDS pass cost more than the 60 conversions per item they save); the
                         // fused stem writes its patch as fp32 directly (84 -> 78 us)

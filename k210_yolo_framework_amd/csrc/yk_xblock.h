@@ -46,6 +46,7 @@ struct xb_args {
     // A tensor whose only consumer is the depthwise conv of another fused block is stored as FP32 ([pixel][group][ch 0-3 | ch 4-7], the same
     // 32 bytes per group as (hi | lo), exponent 0): its producer skips the split, its consumer's taps skip 72 conversions per item
     int src_f32, dst_f32;
+    int bt_bytes, lds_bytes;           // pointwise weight tile in LDS: 2 KB per 16-channel block that EXISTS (N = 96 in a 128-wide tile: 12 KB, not 16), total dynamic LDS
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw, fd_nk;
     // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
     // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
@@ -183,9 +184,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
 #define XB_STAMP(k)
 #endif
     XB_STAMP(0)
-    const int STG = C::stage(a.n16p);
+    const int STG = a.n16p * 32 + C::PARB + a.bt_bytes;
     unsigned char *A = xsm + (a.db ? 2 : 1) * STG;
-    float *sf = reinterpret_cast<float *>(xsm + C::lds(a.n16p, a.db) - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
+    float *sf = reinterpret_cast<float *>(xsm + a.lds_bytes - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
     uint32_t *smax = reinterpret_cast<uint32_t *>(sf + 8);
     // block -> (image, tile); blockIdx.y = N slice
     const int bid = x_xcd_tile(blockIdx.x, gridDim.x);
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
 #pragma unroll
         for (int it = 0; it < (BN / 16 * 2 + 3) / 4; ++it) {
             const int pc = it * 4 + wid;
-            if (pc < BN / 16 * 2) {
+            if (pc * 1024 < a.bt_bytes) {
                 const uint32_t ob = ws + (uint32_t)pc * 1024u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Bs + pc * 1024), 16, ob, 0, 0, 0);
             }
