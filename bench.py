@@ -472,22 +472,26 @@ def main():
                 pass
         # every launch against its own bound, and the time-weighted step fraction per kernel family: the largest launch alone hides
         # where the step really spends its time
-        fam, t_roof_sum = {}, 0.0
-        for i, (nm, fl, by) in enumerate(launches):
-            t_roof = max(by * B * basis / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_PEAK_TFLOPS * 1e12)) * 1e6
-            key = ('late backbone (cluster launch)' if nm.startswith('x:persist') else 'heads (cluster launch)' if nm.startswith('x:heads') else
-                   'stem' if 'stem' in nm else 'u8_max' if 'u8_max' in nm else 'dw+pw block' if ('dw3x3' in nm and 'conv1x1' in nm) else
-                   'depthwise' if 'dw3x3' in nm else 'conv3x3' if 'conv3x3' in nm else 'split-K finish' if 'splitk_reduce' in nm else 'conv1x1')
-            f = fam.setdefault(key, [0.0, 0.0, 0])
-            f[0] += float(ms[i]) * 1e3
-            f[1] += t_roof
-            f[2] += 1
-            t_roof_sum += t_roof
+        def families(launches_, ms_):
+            fam_, t_sum = {}, 0.0
+            for i, (nm, fl, by) in enumerate(launches_):
+                t_roof = max(by * B * basis / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_PEAK_TFLOPS * 1e12)) * 1e6
+                key = ('late backbone (cluster launch)' if nm.startswith('x:persist') else 'heads (cluster launch)' if nm.startswith('x:heads') else
+                       'stem' if 'stem' in nm else 'u8_max' if 'u8_max' in nm else 'dw+pw block' if ('dw3x3' in nm and 'conv1x1' in nm) else
+                       'depthwise' if 'dw3x3' in nm else 'conv3x3' if 'conv3x3' in nm else 'split-K finish' if 'splitk_reduce' in nm else 'conv1x1')
+                f = fam_.setdefault(key, [0.0, 0.0, 0])
+                f[0] += float(ms_[i]) * 1e3
+                f[1] += t_roof
+                f[2] += 1
+                t_sum += t_roof
+            return ({k: {'launches': v[2], 'us': round(v[0], 1), 'roofline_us': round(v[1], 1), 'frac': round(v[1] / v[0], 3)}
+                     for k, v in sorted(fam_.items(), key=lambda kv: -kv[1][0])}, t_sum)
+        fam, t_roof_sum = families(launches, ms)
+        lat_fam, lat_roof_sum = families(lat_launches, lat_ms)
         roof.update({'kernel': name, 'avg_us': round(float(ms[dom]) * 1e3, 2), 'algorithmic_bytes_per_launch': int(alg_bytes),
                      'sum_kernels_us': round(float(ms.sum()) * 1e3, 1),
                      'step_frac_time_weighted': round(t_roof_sum / (float(ms.sum()) * 1e3), 4),
-                     'families': {k: {'launches': v[2], 'us': round(v[0], 1), 'roofline_us': round(v[1], 1), 'frac': round(v[1] / v[0], 3)}
-                                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
+                     'families': fam,
                      'per_kernel_us': {f'{i}:{launches[i][0]}': round(float(ms[i]) * 1e3, 2) for i in range(len(ms))}})
         alg_gb = spec.act_elems_per_image() * 2 * B / 1e9                     # in + out of every conv layer once, fp16
         alg_gflop = 2.0 * spec.macs_per_image() * B / 1e9
@@ -514,6 +518,7 @@ def main():
                                                     'two launches of per-image workgroup clusters)',
                                             'schedule': sched_lat, 'launches_per_step': len(lat_launches) + 3,
                                             'sum_kernels_us': round(float(lat_ms.sum()) * 1e3, 1),
+                                            'step_frac_time_weighted': round(lat_roof_sum / (float(lat_ms.sum()) * 1e3), 4), 'families': lat_fam,
                                             'per_kernel_us': {f'{i}:{lat_launches[i][0][:72]}': round(float(lat_ms[i]) * 1e3, 2) for i in range(len(lat_ms))}},
                        'host_us_per_step': round(host_us, 1),
                        'from_host_host_us_per_step': None if fh_host_us is None else round(fh_host_us, 1), 'batches_in_flight': S, 'precision': args.precision,
