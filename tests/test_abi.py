@@ -128,3 +128,14 @@ def test_package_import_asks_for_one_hardware_queue_per_pipeline_stream():
     code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '2'; import k210_yolo_framework_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=str(ROOT))
     assert out.stdout.strip() == '2', out.stderr
+
+
+def test_schedule_and_precision_constants_match_the_header():
+    """engine.py passes `precision | schedule` to yk_plan_create_ex: the numbers must be the header's."""
+    from k210_yolo_framework_amd import engine
+    txt = HEADER.read_text()
+    val = lambda name: int(re.search(rf'#define\s+{name}\s+(0x[0-9a-fA-F]+|\d+)', txt).group(1), 0)
+    assert engine.PRECISIONS == {'f16': val('YK_PRECISION_F16'), 'f16x2': val('YK_PRECISION_F16X2')}
+    assert engine.SCHEDULES == {'throughput': val('YK_SCHEDULE_THROUGHPUT'), 'latency': val('YK_SCHEDULE_LATENCY')}
+    assert all((v & val('YK_SCHEDULE_MASK')) == v for v in engine.SCHEDULES.values())
+    assert all((v & val('YK_SCHEDULE_MASK')) == 0 for v in engine.PRECISIONS.values())
