@@ -522,6 +522,43 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
     float4 scu[TN];                                                   // BN scale with the middle exponent folded in (a power of two: exact)
 #pragma unroll
     for (int j = 0; j < TN; ++j) scu[j] = float4{sc[j].x * umid, sc[j].y * umid, sc[j].z * umid, sc[j].w * umid};
+    if (a.dst_f32 && !a.res.p) {
+        // fp32 output (its only reader is another fused block's depthwise conv): a lane's four channels are 16 contiguous bytes of the
+        // tensor and the four lanes of a pixel cover 64 - stored straight from the registers.  (The (hi | lo) layout leaves 8-byte
+        // pieces per lane, which is why that form is staged through LDS below; here the staging would be 33 KB written + 33 KB read on
+        // the launch's busiest unit, a barrier and a copy-out loop for nothing.)
+        if (wave_live) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int p = i * 16 + fr;
+                const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                const bool mok = py < a.TH && oy < a.Ho && ox < a.Wo;
+                const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + (wid * TN + j) * 16 + nl4;
+                    float v[4];
+                    v[0] = x_actf(__builtin_fmaf(acc[i][j][0], scu[j].x, bs[j].x), a.slope, a.cap);
+                    v[1] = x_actf(__builtin_fmaf(acc[i][j][1], scu[j].y, bs[j].y), a.slope, a.cap);
+                    v[2] = x_actf(__builtin_fmaf(acc[i][j][2], scu[j].z, bs[j].z), a.slope, a.cap);
+                    v[3] = x_actf(__builtin_fmaf(acc[i][j][3], scu[j].w, bs[j].w), a.slope, a.cap);
+                    if (mok && (n >> 3) < a.outG) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rmax = fmaxf(rmax, fabsf(v[k]));
+                        *reinterpret_cast<u32x4 *>(a.out + (m * a.outG + (n >> 3)) * 32 + ((n >> 2) & 1) * 16) =
+                            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    }
+                }
+            }
+        }
+        x_amax_lds(smax, 0, rmax);
+        __syncthreads();
+        if (tid == 0 && smax[0]) x_amax_global(a.amax_out + (size_t)b * XS, smax[0]);
+        XB_STAMP(9)
+        XB_STAMP(10)
+        return;
+    }
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += IPP) {
         if (i0 > 0) __syncthreads();                                  // the previous pass has been copied out
