@@ -171,6 +171,7 @@ struct xg_args {
     float slope, cap;
     float gain0, gain1, off;    // |conv output before act| <= gain0*amax(s0) + gain1*amax(s1) + off
     uint8_t *out;               // split tensor, or null for a network output
+    int dst_f32;                // ... stored as fp32 planes [pixel][group][ch 0-3 | ch 4-7], exponent 0: its only reader is a depthwise conv
     int outG;
     float *out32;               // network output [M][N] fp32 (exact pitch)
     int *eexp_out;
@@ -211,7 +212,7 @@ __device__ __forceinline__ void xg_prep(const xg_args &a, int b0, int bl, float 
             bound += x_amax_wave(a.res.amax, b);
             rup = x_pow2(a.res.eexp[b]);
         }
-        const int eo = x_exp_of(__float_as_uint(bound));
+        const int eo = a.dst_f32 ? 0 : x_exp_of(__float_as_uint(bound));
         if (lane == 0) {
             s_up[b - b0] = x_pow2(e1);
             s_resc[b - b0] = x_pow2(e0 - e1);
@@ -256,6 +257,15 @@ __device__ __forceinline__ void xg_epilogue(const xg_args &a, floatx4 (&acc)[BM 
                 }
                 continue;
             }
+            if (a.dst_f32) {                                       // 16 contiguous bytes per lane, 64 per pixel and channel block: no staging
+                if (mok && (n >> 3) < a.outG) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rmax = fmaxf(rmax, fabsf(v[k]));
+                    *reinterpret_cast<u32x4 *>(a.out + ((size_t)m * a.outG + (n >> 3)) * 32 + ((n >> 2) & 1) * 16) =
+                        u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                }
+                continue;
+            }
             if (a.res.p && mok && (n >> 3) < a.res.G) {
                 const uint8_t *q = a.res.p + ((size_t)m * a.res.G + (n >> 3)) * 32 + (n & 7) * 2;
                 const half4 rh = *reinterpret_cast<const half4 *>(q), rl = *reinterpret_cast<const half4 *>(q + 16);
@@ -278,6 +288,10 @@ __device__ __forceinline__ void xg_epilogue(const xg_args &a, floatx4 (&acc)[BM 
     }
     if (a.out32) return;
     __syncthreads();
+    if (a.dst_f32) {
+        if (a.amax_out && tid <= bl - b0 && s_amax[tid]) x_amax_global(a.amax_out + (size_t)(b0 + tid) * XS, s_amax[tid]);
+        return;
+    }
     // 16 bytes per lane, row-contiguous: a pixel's BN channels are BN*4 bytes in a row of the output tensor
     constexpr int VPR = BN / 4;
     for (int v = tid; v < BM * VPR; v += C::NT) {
@@ -577,6 +591,7 @@ struct xdw_args {
     // geometry, fixed at plan creation
     int TH, TW, PH, PW, GS, gsl, tiles_x, tiles_y, NT, n16, n16p;
     int dbg;
+    int in_f32;                        // the input is stored as fp32 planes (its only reader is this kernel): the taps read floats
     yk_fastdiv fd_gsl, fd_tpi, fd_tx, fd_gs, fd_pw, fd_tw;
 };
 __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
@@ -647,10 +662,17 @@ __global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
                 const int at = (base + ((t / 3) * a.PW + (t % 3)) * a.GS) * 16;
                 const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
                 const float2v w2[4] = {{w0[t].x, w0[t].y}, {w0[t].z, w0[t].w}, {w1[t].x, w1[t].y}, {w1[t].z, w1[t].w}};
+                if (a.in_f32) {                                  // (h, l) are the fp32 planes: channels 0-3 | 4-7
+                    acc2[0] = __builtin_elementwise_fma(float2v{__uint_as_float(h[0]), __uint_as_float(h[1])}, w2[0], acc2[0]);
+                    acc2[1] = __builtin_elementwise_fma(float2v{__uint_as_float(h[2]), __uint_as_float(h[3])}, w2[1], acc2[1]);
+                    acc2[2] = __builtin_elementwise_fma(float2v{__uint_as_float(l[0]), __uint_as_float(l[1])}, w2[2], acc2[2]);
+                    acc2[3] = __builtin_elementwise_fma(float2v{__uint_as_float(l[2]), __uint_as_float(l[3])}, w2[3], acc2[3]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                    // hi + lo back in fp32 (one op per channel), packed fp32 FMA on channel pairs
-                    const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
-                    acc2[j] = __builtin_elementwise_fma(x2, w2[j], acc2[j]);
+                    for (int j = 0; j < 4; ++j) {                // hi + lo back in fp32 (one op per channel), packed fp32 FMA on channel pairs
+                        const float2v x2 = {x_mix_sum_lo(h[j], l[j]), x_mix_sum_hi(h[j], l[j])};
+                        acc2[j] = __builtin_elementwise_fma(x2, w2[j], acc2[j]);
+                    }
                 }
             }
             const float acc[8] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
@@ -1228,7 +1250,7 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
             q.type = XP_LOAD;
             q.H = d.in.H; q.W = d.in.W; q.Gs = Gs_in;
             q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
-            q.src = d.in.p; q.src_eexp = d.in.eexp; q.src_amax = d.in.amax; q.tG = d.in.G;
+            q.src = d.in.p; q.src_eexp = d.in.eexp; q.src_amax = d.in.amax; q.tG = d.in.G; q.src_f32 = d.in_f32;
             ph.push_back(q);
         }
         {
@@ -1289,7 +1311,7 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
             q.type = XP_STORE;
             q.H = d.Ho; q.W = d.Wo; q.Gs = Gs_out;
             q.fd_w = yk_make_fastdiv((uint32_t)q.W); q.fd_gs = yk_make_fastdiv((uint32_t)q.Gs);
-            q.dst = g.out; q.dst_eexp = g.eexp_out; q.dst_amax = g.amax_out; q.tG = g.outG;
+            q.dst = g.out; q.dst_eexp = g.eexp_out; q.dst_amax = g.amax_out; q.tG = g.outG; q.dst_f32 = g.dst_f32;
             ph.push_back(q);
         }
     }
@@ -2061,22 +2083,28 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         l.name = nm;
         p->L.push_back(l);
     }
-    // A fused block's output that only ANOTHER fused block's depthwise conv reads is stored as fp32 (yk_xblock.h: no split in the producer,
-    // no conversions in the consumer's nine taps)
+    // A tensor whose ONLY reader is a depthwise conv (of a fused block, a plain depthwise launch or the persistent stage's first phase) is
+    // stored as fp32 planes - the same 32 bytes per channel group as (hi | lo): its producer (fused block or conv launch without a residual)
+    // skips the split and stores straight from the registers, the depthwise taps skip their conversions
     if (!yk_dev_env("YK_XB_NOF32"))
-        for (size_t i = 0; i < p->L.size(); ++i) {
-            if (p->L[i].kind != XK_BLOCK || !p->L[i].b.out) continue;
-            int tid = -1;
-            for (size_t t = 0; t < p->T.size(); ++t)
-                if (p->T[t].d == p->L[i].b.out) tid = (int)t;
-            if (tid < 0 || p->T[tid].uses != 1) continue;
-            for (size_t j = i + 1; j < p->L.size(); ++j)
-                if (p->L[j].kind == XK_BLOCK && !p->L[j].b.stem && p->L[j].b.in.p == p->L[i].b.out) {
-                    p->L[i].b.dst_f32 = 1;
-                    p->L[j].b.src_f32 = 1;
-                    p->T[tid].f32 = true;
-                    break;
-                }
+        for (size_t t = 1; t < p->T.size(); ++t) {
+            xtens &T = p->T[t];
+            if (!T.d || T.uses != 1 || T.net_out || T.is_input) continue;
+            xlaunch *prod = nullptr, *cons = nullptr;
+            for (xlaunch &l : p->L) {
+                if (l.kind == XK_BLOCK && l.b.out == T.d && !l.b.res.p) prod = &l;
+                if (l.kind == XK_CONV && l.c.out == T.d && !l.c.res.p) prod = &l;
+                if (l.kind == XK_BLOCK && !l.b.stem && l.b.in.p == T.d) cons = &l;
+                if (l.kind == XK_DW && l.d.in.p == T.d) cons = &l;
+            }
+            bool other = false;                                            // read as a matrix operand / residual somewhere: stays (hi | lo)
+            for (xlaunch &l : p->L)
+                other = other || (l.kind == XK_BLOCK && l.b.res.p == T.d) || (l.kind == XK_CONV && (l.c.s0.p == T.d || l.c.s1.p == T.d || l.c.res.p == T.d)) ||
+                        (l.kind == XK_POOL && l.p.in.p == T.d) || (l.kind == XK_ADD && (l.ad.x.p == T.d || l.ad.y.p == T.d));
+            if (other || !prod || !cons) continue;
+            if (prod->kind == XK_BLOCK) prod->b.dst_f32 = 1; else prod->c.dst_f32 = 1;
+            if (cons->kind == XK_BLOCK) cons->b.src_f32 = 1; else cons->d.in_f32 = 1;
+            T.f32 = true;
         }
     // The two cluster launches hold every CU for their whole duration: the shortest time of ONE batch (one-batch latency 669 -> 542 us of
     // kernels), but with several batches in flight on several streams the launch-per-layer form overlaps better (78 k vs 68 k images/s, four in

@@ -56,6 +56,7 @@ struct xp_phase {
     int *dst_eexp;
     uint32_t *dst_amax;
     int tG;                            // channel groups of that tensor
+    int src_f32, dst_f32;              // XP_LOAD / XP_STORE: the tensor is stored as fp32 planes (exponent 0)
     int barrier_after;
     // the depthwise phase that follows a LOAD / PW phase: its parameter slice is requested while this phase runs
     const float *nd_par;
@@ -170,10 +171,15 @@ __device__ __forceinline__ float xp_load(const xp_phase &P, int b, int j) {
         const uint8_t *s = P.src + (((size_t)b * P.H * P.W + p) * P.tG + j * P.Gs + g) * 32;
         const u32x4 h = *reinterpret_cast<const u32x4 *>(s), l = *reinterpret_cast<const u32x4 *>(s + 16);
         float4 v0, v1;
+        if (P.src_f32) {
+            v0 = float4{__uint_as_float(h[0]) * up, __uint_as_float(h[1]) * up, __uint_as_float(h[2]) * up, __uint_as_float(h[3]) * up};
+            v1 = float4{__uint_as_float(l[0]) * up, __uint_as_float(l[1]) * up, __uint_as_float(l[2]) * up, __uint_as_float(l[3]) * up};
+        } else {
         v0.x = x_mix_sum_lo(h[0], l[0]) * up; v0.y = x_mix_sum_hi(h[0], l[0]) * up;
         v0.z = x_mix_sum_lo(h[1], l[1]) * up; v0.w = x_mix_sum_hi(h[1], l[1]) * up;
         v1.x = x_mix_sum_lo(h[2], l[2]) * up; v1.y = x_mix_sum_hi(h[2], l[2]) * up;
         v1.z = x_mix_sum_lo(h[3], l[3]) * up; v1.w = x_mix_sum_hi(h[3], l[3]) * up;
+        }
         const int q = (py + 1) * W2 + px + 1;
         *reinterpret_cast<float4 *>(xsm + (q * P.Gs + g) * 16) = v0;
         *reinterpret_cast<float4 *>(xsm + ypl + (q * P.Gs + g) * 16) = v1;
@@ -186,7 +192,7 @@ __device__ __forceinline__ float xp_load(const xp_phase &P, int b, int j) {
 
 // ---- XP_STORE: y -> the workgroup's channel slice of a stored tensor ----------------------------------------------------
 __device__ __forceinline__ void xp_store(const xp_phase &P, int b, int j, float bound, uint32_t *s_max) {
-    const int eo = x_exp_of(__float_as_uint(bound));
+    const int eo = P.dst_f32 ? 0 : x_exp_of(__float_as_uint(bound));
     const float down = x_pow2(-eo);
     const uint32_t ypl = xp_ypl(P);
     const int n = P.H * P.W * P.Gs, W2 = P.W + 2;
@@ -204,9 +210,14 @@ __device__ __forceinline__ void xp_store(const xp_phase &P, int b, int j, float 
             mx = fmaxf(mx, fabsf(v[k]));
             vd[k] = v[k] * down;
         }
+        uint8_t *d = P.dst + (((size_t)b * P.H * P.W + p) * P.tG + j * P.Gs + g) * 32;
+        if (P.dst_f32) {
+            *reinterpret_cast<float4 *>(d) = v0;
+            *reinterpret_cast<float4 *>(d + 16) = v1;
+            continue;
+        }
         half8 hi, lo;
         x_split8(vd, hi, lo);
-        uint8_t *d = P.dst + (((size_t)b * P.H * P.W + p) * P.tG + j * P.Gs + g) * 32;
         *reinterpret_cast<half8 *>(d) = hi;
         *reinterpret_cast<half8 *>(d + 16) = lo;
     }
