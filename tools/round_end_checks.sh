@@ -1,7 +1,9 @@
 #!/bin/bash
+# Run ON THE GPU BOX (through gpurun) at the end of a round: profile refresh + bench line (tools/refresh_profiles4.sh full), the whole -m gpu suite,
+# the sanitizer flavours (tools/run_asan.sh) and __graft_entry__.smoke().
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/c23
-O=gpurun_out/c23
+mkdir -p gpurun_out/round_end
+O=gpurun_out/round_end
 export TMPDIR=/tmp
 bash tools/refresh_profiles4.sh full > $O/refresh.log 2>&1
 tail -5 $O/refresh.log | cut -c1-300
