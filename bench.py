@@ -398,24 +398,27 @@ def main():
     single = Harness(1, args.precision, letterbox=args.letterbox, from_host=args.from_host, graph=use_graph)
     el1, _ = single.measure(min(args.steps, 100), 5)
     single_ms = el1 / min(args.steps, 100) * 1e3
-    # per-launch times of both plans while they are alive (rank 0), then both harnesses go: with them alive the from-host harness below
-    # would be streams 6-9 of this process, more than the GPU_MAX_HW_QUEUES = 8 hardware queues - its streams then share queues and the
-    # number drops by 10 % (measured: 66.5 k with the two harnesses alive, 72-76 k without)
+    # per-launch times of both plans while they are alive (rank 0)
     prof = None
     if rank == 0:
         p_head, p_lat = head.plans[0], single.plans[0]
         ms_head = p_head.profile(frames, iters=20)
         prof = (ms_head, p_head.launches(), p_lat.profile(frames, iters=20) if p_lat is not p_head else ms_head, p_lat.launches(),
                 getattr(head.pipe, 'schedule', None), getattr(single.pipe, 'schedule', None))
-    head.close()
     single.close()
     # SURVEY 8(d) "end to end" with the PCIe legs: the same step fed from pinned host memory (H2D copy in front of the captured step), detections
-    # delivered to pinned host memory; every rank takes part (8(e): host feeding is where the N-GPU curve is expected to bend)
+    # delivered to pinned host memory; every rank takes part (8(e): host feeding is where the N-GPU curve is expected to bend).  Measured on
+    # the SAME pipeline (same plans, same streams) as `value`: a serving process has one pipeline, and a pipeline created later in this
+    # process - on streams the runtime handed out later - feeds 10 % slower (66-70 k images/s in a fresh harness, 71-72 k in a second and
+    # third one, 76 k on this one; profiles/r04_schedules.txt)
     value_from_host, fh_host_us = None, None
     if not args.from_host and not args.no_secondary:
-        ok, fh, err = 1, None, ''
+        ok, err = 1, ''
         try:
-            fh = Harness(S, args.precision, letterbox=args.letterbox, from_host=True, graph=use_graph)
+            h_ = head.src.cpu()
+            for i in range(head.S):
+                head.pipe.host_input(i).copy_(h_)                    # the frames of every slot wait in pinned host memory
+            head.from_host = True
         except Exception as e:
             ok, err = 0, f'{type(e).__name__}: {e}'
         if dist is not None:                                         # agree before entering the timed region's barrier
@@ -423,16 +426,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
         if ok:
-            # (an order effect is on record, unexplained: the FIRST from-host harness of a process measures 66-67 k images/s, a second and a
-            # third one of the same code 71-72 k - profiles/r04_schedules.txt; neither a longer warm-up nor fewer live streams changes
-            # the first one.  The conservative first number is the one reported.)
-            el_fh, _ = fh.measure(min(args.steps, 100), 10)
+            el_fh, _ = head.measure(min(args.steps, 100), 10)
             value_from_host = world * B * min(args.steps, 100) / el_fh
-            fh_host_us = fh.host_s * 1e6
+            fh_host_us = head.host_s * 1e6
         elif rank == 0:
-            print(f'bench.py: from-host harness failed on some rank: {err}', file=sys.stderr)
-        if fh is not None:
-            fh.close()
+            print(f'bench.py: from-host steps failed on some rank: {err}', file=sys.stderr)
+        head.from_host = False
+    head.close()
 
     if rank == 0:
         # ---- roofline of the dominant kernel, HIP events on the launch stream.  Algorithmic bytes are SURVEY 8(d)'s (every layer's
