@@ -38,6 +38,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # one hardware queue per stream in flight (k210_yolo_framework_amd/__init__.py), before any HIP call
+os.environ.setdefault('OMP_PROC_BIND', 'close')   # cpu_baseline: OpenMP teams bound to cores (before libgomp initialises), or the thread probe reads noise
+os.environ.setdefault('OMP_PLACES', 'cores')
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -66,12 +68,17 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
     cands = sorted({n for n in (8, 16, 32, 64, 96, 128, physical, logical) if n <= logical})
     x0 = oracle.normalise_u8(rng.integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8))
 
+    dec_threads = [1]
+
     def decode(outs, n):
-        decode_ref.decode_batch([o.reshape(n, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors, spec.in_hw, spec.in_hw, 0.7, 0.5)
+        # the per-class mask + greedy NMS in C (oracle/decode_nms_ref.c, bit-equal to decode_ref.py: tests/test_oracle_decode.py), images in
+        # parallel on the build's own thread count - round 4 timed decode_ref.py's one-thread Python loop here, 60 % of the chain
+        decode_ref.decode_batch_fast([o.reshape(n, o.shape[1], o.shape[2], spec.anchor_num, -1) for o in outs], anchors, spec.in_hw, spec.in_hw,
+                                     0.7, 0.5, threads=dec_threads[0])
 
     def chain(fwd, budget):
         t_total, t_fwd, n = 0.0, 0.0, 0
-        while t_total < budget and n < 512:
+        while t_total < budget and n < 2048:
             frames = rng.integers(0, 256, (B, *spec.in_hw, 3), dtype=np.uint8)
             t0 = time.perf_counter()
             outs = fwd(oracle.normalise_u8(frames))
@@ -83,16 +90,21 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
             n += B
         return n / t_total, n, t_total, n / t_fwd
     res, used, probes = {}, {}, {}
-    # (1) the C port: its OpenMP team is probed on 8 frames (a team of every logical CPU spin-waits at each loop barrier)
+    # (1) the C port: its OpenMP team is probed on the full 32-frame batch, best of two passes per team size (threads bound to cores:
+    # OMP_PROC_BIND / OMP_PLACES are set at the top of this file, before libgomp starts; round 4 probed 8 frames unbound and read noise)
     pr = {}
     for nt in [c for c in cands if c <= 128]:
         oracle.set_threads(nt)
-        t0 = time.perf_counter()
-        oracle.net_forward(plan, x0[:8], emulate_f16=False, out_ids=spec.outputs)
-        pr[nt] = time.perf_counter() - t0
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            oracle.net_forward(plan, x0, emulate_f16=False, out_ids=spec.outputs)
+            best = min(best, time.perf_counter() - t0)
+        pr[nt] = best
     used['port'] = min(pr, key=pr.get)
-    probes['port'] = {k: round(8 / v, 1) for k, v in pr.items()}
+    probes['port'] = {k: round(B / v, 1) for k, v in pr.items()}
     oracle.set_threads(used['port'])
+    dec_threads[0] = min(B, used['port'])
     res['port'] = chain(lambda x: oracle.net_forward(plan, x, emulate_f16=False, out_ids=spec.outputs), budget_s / 2)
     # (2) torch-CPU / oneDNN, parameters converted once; layout and pool size probed
     pr = {}
@@ -109,17 +121,19 @@ def cpu_baseline(spec, weights, anchors, budget_s=12.0):
     probes['graph'] = {f'{k[0]}{"cl" if k[1] else ""}': round(B / v, 1) for k, v in pr.items()}
     torch.set_num_threads(nt)
     model = torch_net_ref.Prepared(spec, weights, torch.float32, channels_last=cl)
+    dec_threads[0] = min(B, nt)
     res['graph'] = chain(model, budget_s / 2)
     best = max(res, key=lambda k: res[k][0])
     names = {'port': 'oracle/yolo_net_ref.c (C restatement of the Keras graph, OpenMP)',
              'graph': f'oracle/torch_net_ref.Prepared (torch-CPU / oneDNN build of the same Keras graph, {"channels_last" if cl else "NCHW"})'}
     return {'value': round(res[best][0], 1), 'unit': 'images/sec', 'cores': used[best], 'kind': 'port', 'build': names[best],
             'host_logical_cpus': logical, 'host_physical_cores': physical,
-            'sample': f'batches of 32 synthetic 224x320 frames, normalise + fp32 conv stack + decode_ref.py NMS; '
+            'sample': f'batches of 32 synthetic 224x320 frames, normalise + fp32 conv stack + decode_ref.py boxes/scores + per-class NMS in C '
+                      f'(oracle/decode_nms_ref.c, images in parallel); '
                       f'C port on {used["port"]} threads: {res["port"][0]:.1f} images/s over {res["port"][1]} frames ({res["port"][2]:.1f} s); '
                       f'torch-CPU on {used["graph"]} threads: {res["graph"][0]:.1f} images/s over {res["graph"][1]} frames ({res["graph"][2]:.1f} s)',
             'port_images_per_sec': round(res['port'][0], 1), 'torch_cpu_images_per_sec': round(res['graph'][0], 1),
-            # the decode of this leg is decode_ref.py (numpy, one thread; random weights give ~350 boxes per image): without it
+            # the conv stack alone (random weights give ~350 boxes per image; the decode is numpy box arithmetic + the C NMS helper)
             'conv_stack_only_images_per_sec': {'port': round(res['port'][3], 1), 'torch_cpu': round(res['graph'][3], 1)},
             'thread_probe_images_per_sec': probes}
 
@@ -298,6 +312,7 @@ def main():
     ap.add_argument('--precision', choices=['f16', 'f16x2'], default='f16x2',
                     help="'f16x2' (default): the mode that meets BASELINE.json's 1e-3 / exact-set tolerance; 'f16': fp16 storage, 5e-3 worst case")
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host (no hipGraph replay of the step)')
+    ap.add_argument('--no-numa-bind', action='store_true', help='leave the process on whatever CPUs the launcher gave it')
     ap.add_argument('--stub', action='store_true', help='no GPU: sleeping step over gloo (launcher / rendezvous self-test)')
     ap.add_argument('--mode', choices=['inference', 'train'], default='inference',
                     help="'train': BASELINE configs[3] (yolo_mobilev2 1.0 training step, 16 images/GPU, RCCL gradient all-reduce)")
@@ -317,6 +332,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     engine.require_gpu()
     torch.cuda.set_device(local)
+    # the N-GPU curve bends at host feeding - this rank's submit loop, producer threads and pinned frame ring go on the NUMA
+    # node its GPU hangs off, before anything pinned is allocated (shard.bind_to_gpu_numa; a no-op on a single-node host)
+    from k210_yolo_framework_amd import shard as _shard
+    full_affinity = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
+    numa = {'node': -1, 'cpus': None} if args.no_numa_bind else _shard.bind_to_gpu_numa(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -363,7 +383,7 @@ def main():
             for _ in range(max(warmup, 3)):
                 self.step()
             sync_all()
-            times, host = [], []
+            times, host, local_times = [], [], []
             while True:
                 sync_all()
                 t0 = time.perf_counter()
@@ -372,6 +392,7 @@ def main():
                 t1 = time.perf_counter()
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
+                local_times.append(el)
                 if dist is not None:
                     from k210_yolo_framework_amd import shard
                     dist.barrier()
@@ -381,6 +402,7 @@ def main():
                 if sum(times) >= min_s or len(times) >= max_regions:
                     break
             self.host_s = statistics.median(host)                 # host time to SUBMIT one step (the GPU runs behind it)
+            self.local_s = statistics.median(local_times)         # this rank's own time for the region (before the max over ranks)
             return statistics.median(times), len(times)
 
         def close(self):
@@ -411,7 +433,7 @@ def main():
     # the SAME pipeline (same plans, same streams) as `value`: a serving process has one pipeline, and a pipeline created later in this
     # process - on streams the runtime handed out later - feeds 10 % slower (66-70 k images/s in a fresh harness, 71-72 k in a second and
     # third one, 76 k on this one; profiles/r04_schedules.txt)
-    value_from_host, fh_host_us = None, None
+    value_from_host, fh_host_us, per_rank_fh = None, None, None
     if not args.from_host and not args.no_secondary:
         ok, err = 1, ''
         try:
@@ -429,6 +451,14 @@ def main():
             el_fh, _ = head.measure(min(args.steps, 100), 10)
             value_from_host = world * B * min(args.steps, 100) / el_fh
             fh_host_us = head.host_s * 1e6
+            mine = B * min(args.steps, 100) / head.local_s                       # this rank's own from-host rate
+            if dist is not None:
+                t = torch.zeros(world, dtype=torch.float64, device='cuda')
+                t[rank] = mine
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                per_rank_fh = [round(float(v), 1) for v in t.cpu().tolist()]
+            else:
+                per_rank_fh = [round(mine, 1)]
         elif rank == 0:
             print(f'bench.py: from-host steps failed on some rank: {err}', file=sys.stderr)
         head.from_host = False
@@ -503,6 +533,8 @@ def main():
             'value': round(value, 1), 'value_from_host': None if value_from_host is None else round(value_from_host, 1),
             'from_host_frac_of_value': None if value_from_host is None else round(value_from_host / value, 3),
             'from_host_h2d_GBps': None if value_from_host is None else round(value_from_host / world * 224 * 320 * 3 / 1e9, 2),
+            'from_host_per_rank': None if per_rank_fh is None else {'images_per_sec': per_rank_fh, 'min': min(per_rank_fh), 'max': max(per_rank_fh)},
+            'host_placement': {'numa_node_of_gpu': numa.get('node'), 'cpus_bound': numa.get('cpus'), 'pci': numa.get('pci')},
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16 storage / f32 accumulate' if args.precision == 'f16' else 'f16x2 (compensated fp16 MFMA operands: x = hi + lo, fp32 accumulate)',
@@ -580,6 +612,8 @@ def main():
             out['secondary'] = sec
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            if full_affinity is not None:
+                os.sched_setaffinity(0, full_affinity)                # the CPU baseline gets every host core back
             out['cpu_baseline'] = cpu_baseline(spec, weights, VOC_ANCHORS)
         print(json.dumps(out))
     if dist is not None:

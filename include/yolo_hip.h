@@ -169,6 +169,10 @@ int yk_get_output(yk_plan_t *p, int idx, float **d_ptr, size_t *bytes, int *h, i
 /* Synchronises the device and returns an error if an earlier asynchronous run of this plan failed ON the device (the f16x2 mode's
  * persistent stage bounds every inter-workgroup wait and gives up rather than hang: then this call says so).  YK_OK otherwise. */
 int yk_plan_check(yk_plan_t *p);
+/* The same sticky word without waiting for the device (a read of mapped host memory): *error_out != 0 means a run that has already
+ * FINISHED failed on the device; the caller has synchronised with the runs it asks about (event / stream).  clear != 0 resets it. */
+int yk_plan_peek_error(yk_plan_t *plan, int clear, unsigned *error_out);
+int yk_plan_debug_set_error(yk_plan_t *plan, unsigned value); /* test hook: what a failing cluster launch stores */
 
 /* Debug/parity access to any intermediate activation (fp16, channel pitch padded
  * to a multiple of 8): copies tensor `tid` of the last run to host as fp32 NHWC. */
@@ -238,6 +242,17 @@ void yk_graph_destroy(yk_graph_t *g);
 int yk_memcpy_async(void *dst, const void *src, size_t bytes, void *stream);
 /* Device address of pinned host memory (hipHostGetDevicePointer): the form of a host buffer a kernel can write. */
 int yk_host_device_ptr(void *h_ptr, void **d_ptr);
+/* A HIP stream created by the library itself (hipStreamCreateWithPriority, non-blocking; priority 0 = default, negative = higher):
+ * the ROCm runtime binds a stream to one of its GPU_MAX_HW_QUEUES hardware queues in creation order, so a pipeline that creates its
+ * own streams back to back gets distinct queues whatever pooled streams the host framework handed out before.
+ * yk_stream_query_priority returns the priority the runtime reports for any stream handle. */
+int yk_stream_create(void **stream_out, int priority);
+int yk_stream_destroy(void *stream);
+int yk_stream_query_priority(void *stream, int *priority_out);
+/* The library keeps per-stream scratch buffers (decode / NMS work space) that grow on demand.  A captured step holds their addresses:
+ * yk_scratch_generation(stream) counts how often a buffer of `stream` (on the current device) has MOVED; the holder of captured graphs
+ * compares it before a replay and re-captures when it changed (engine.Pipeline does). */
+unsigned long long yk_scratch_generation(void *stream);
 
 /* C-mode (region_layer.c:121-283) for a batch of layer outputs without host round trips.
  * d_input element (b, anchor n, entry e, row y, col x) is at

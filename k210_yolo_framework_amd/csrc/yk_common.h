@@ -40,6 +40,7 @@ void yk_set_error(const char *fmt, ...);
 
 // grow-only device scratch per (device, stream); safe because work on one stream is ordered.
 void *yk_scratch(int device, void *stream, int slot, size_t bytes);
+void yk_scratch_release_stream(void *stream);
 
 static inline int yk_current_device() {
     int d = -1;

@@ -147,5 +147,7 @@ int yk_xplan_output(yk_xplan *p, int idx, float **d_ptr, size_t *bytes, int *h, 
 int yk_xplan_read_tensor(yk_xplan *p, int tid, int batch, float *h_dst, size_t dst_elems);
 int yk_xplan_launch_count(const yk_xplan *p);
 int yk_xplan_check(yk_xplan *p);
+unsigned yk_xplan_peek_error(yk_xplan *p, int clear);
+void yk_xplan_debug_set_error(yk_xplan *p, unsigned value);
 int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipStream_t st, long long *h_out, int max_wg);
 int yk_xplan_launch_info(const yk_xplan *p, int i, const char **name, double *flops, double *bytes);

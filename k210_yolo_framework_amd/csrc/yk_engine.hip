@@ -760,6 +760,28 @@ extern "C" int yk_plan_check(yk_plan_t *p) {
     return YK_OK;
 }
 
+// The same word WITHOUT waiting for the device: nonzero = a run that has already finished failed on the device (today: a cluster launch
+// of the f16x2 latency schedule could not assemble a cluster).  The caller has synchronised with the runs it asks about (an event, a
+// stream); `clear` resets the word after reading it.  Costs a host memory read: the word lives in mapped host memory.
+extern "C" int yk_plan_peek_error(yk_plan_t *p, int clear, unsigned *error_out) {
+    if (!p || !error_out) {
+        yk_set_error("yk_plan_peek_error: bad argument");
+        return YK_ERR_ARG;
+    }
+    *error_out = p->x ? yk_xplan_peek_error(p->x, clear) : 0u;
+    return YK_OK;
+}
+
+// test hook: stores `value` into the error word the way a timed-out cluster barrier does
+extern "C" int yk_plan_debug_set_error(yk_plan_t *p, unsigned value) {
+    if (!p || !p->x) {
+        yk_set_error("yk_plan_debug_set_error: needs an f16x2 plan");
+        return YK_ERR_ARG;
+    }
+    yk_xplan_debug_set_error(p->x, value);
+    return YK_OK;
+}
+
 extern "C" int yk_plan_launch_count(const yk_plan_t *p) { return !p ? 0 : (p->x ? yk_xplan_launch_count(p->x) : (int)p->L.size()); }
 
 extern "C" int yk_plan_launch_info(const yk_plan_t *p, int i, char *name, size_t name_len, double *flops_per_image,
@@ -874,5 +896,32 @@ extern "C" int yk_host_device_ptr(void *h_ptr, void **d_ptr) {
         return YK_ERR_ARG;
     }
     YK_HIP(hipHostGetDevicePointer(d_ptr, h_ptr, 0));
+    return YK_OK;
+}
+
+// library-owned streams (see include/yolo_hip.h): created back to back they land on consecutive hardware queues
+extern "C" int yk_stream_create(void **stream_out, int priority) {
+    if (!stream_out) {
+        yk_set_error("yk_stream_create: bad argument");
+        return YK_ERR_ARG;
+    }
+    hipStream_t s = nullptr;
+    YK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+    *stream_out = (void *)s;
+    return YK_OK;
+}
+extern "C" int yk_stream_destroy(void *stream) {
+    if (!stream) return YK_OK;
+    YK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    yk_scratch_release_stream(stream);
+    YK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return YK_OK;
+}
+extern "C" int yk_stream_query_priority(void *stream, int *priority_out) {
+    if (!priority_out) {
+        yk_set_error("yk_stream_query_priority: bad argument");
+        return YK_ERR_ARG;
+    }
+    YK_HIP(hipStreamGetPriority((hipStream_t)stream, priority_out));
     return YK_OK;
 }

@@ -1156,7 +1156,8 @@ struct yk_xplan {
     unsigned *d_imgmax = nullptr;
     uint32_t *d_amax = nullptr;        // [n_tensors][max_batch][XS], then [max_batch] cluster arrival counters: cleared by every step's first launch
     size_t zero_words = 0;
-    uint32_t *d_err = nullptr;         // sticky device error word (persistent stage: a cluster barrier timed out)
+    uint32_t *d_err = nullptr;         // sticky device error word (a cluster barrier timed out): the device alias of ...
+    uint32_t *h_err = nullptr;         // ... this word of pinned, mapped host memory: the host reads it without a copy or a sync
     int *d_eexp = nullptr;             // [n_tensors][max_batch]
     long long *d_dbg = nullptr;        // developer instrumentation (yk_xplan_phase_stamps)
     int dbg_launch = -1;
@@ -1186,6 +1187,7 @@ static int x_upload_f(yk_xplan *p, const float *src, int n, float mul, const flo
 void yk_xplan_destroy(yk_xplan *p) {
     if (!p) return;
     for (void *q : p->allocs) (void)hipFree(q);
+    if (p->h_err) (void)hipHostFree(p->h_err);
     delete p;
 }
 
@@ -1662,7 +1664,17 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
     p->zero_words = (size_t)n_tensors * max_batch * XS + 2 * (size_t)max_batch * 8 * 2;   // + the barrier granules of the persistent stage and of the heads
     if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
-    if ((rc = x_alloc(p, (void **)&p->d_err, 256))) return fail(rc);
+    {   // the error word lives in mapped host memory: a failing cluster writes it over the link once, the host polls it for free
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            if (h) (void)hipHostFree(h);
+            yk_set_error("yk_plan_create: pinned error word: %s", hipGetErrorString(hipGetLastError()));
+            return fail(YK_ERR_HIP);
+        }
+        memset(h, 0, 256);
+        p->h_err = (uint32_t *)h;
+        p->d_err = (uint32_t *)d;
+    }
     if ((rc = x_alloc(p, (void **)&p->d_eexp, sizeof(int) * (size_t)n_tensors * max_batch))) return fail(rc);
     auto amax_of = [&](int tid) { return p->d_amax + (size_t)tid * max_batch * XS; };
     auto eexp_of = [&](int tid) { return p->d_eexp + (size_t)tid * max_batch; };
@@ -2292,14 +2304,23 @@ int yk_xplan_phase_stamps(yk_xplan *p, int li, const void *d_in, int batch, hipS
 
 // sticky device-side error (a cluster barrier of the persistent stage gave up): synchronises the device
 int yk_xplan_check(yk_xplan *p) {
-    uint32_t e = 0;
     YK_HIP(hipDeviceSynchronize());
-    YK_HIP(hipMemcpy(&e, p->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e) {
-        yk_set_error("f16x2 persistent stage: a workgroup cluster did not assemble (its workgroups were not co-resident); results of that run are invalid");
+    if (yk_xplan_peek_error(p, 1)) {
+        yk_set_error("f16x2 cluster launch: a workgroup cluster did not assemble (its workgroups were not co-resident); results of that run are invalid");
         return YK_ERR_HIP;
     }
     return YK_OK;
+}
+// the error word as it stands now (no synchronisation: meaningful after the caller has waited for the runs it cares about)
+unsigned yk_xplan_peek_error(yk_xplan *p, int clear) {
+    volatile uint32_t *w = p->h_err;
+    const unsigned e = w ? *w : 0u;
+    if (e && clear) *w = 0u;
+    return e;
+}
+
+void yk_xplan_debug_set_error(yk_xplan *p, unsigned value) {
+    if (p->h_err) *(volatile uint32_t *)p->h_err = value;
 }
 
 int yk_xplan_launch_count(const yk_xplan *p) { return (int)p->L.size(); }

@@ -9,8 +9,10 @@
 //
 // Compiled with -ffp-contract=off: every a*b+c stays two roundings, as in the reference's
 // x86-64 build, so thresholds and IoU comparisons see the same fp32 values.
+#include <iterator>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -48,6 +50,9 @@ struct scratch_buf {
 };
 static std::mutex g_scratch_mu;
 static std::map<scratch_key, scratch_buf> g_scratch;
+// how often a scratch buffer of (device, stream) has MOVED (grown past its slack: freed and allocated again).  A captured graph holds
+// the pointers of its capture; a holder of such graphs compares generations before a replay and drops the graphs when they differ.
+static std::map<std::pair<int, void *>, unsigned long long> g_scratch_gen;
 void *yk_scratch(int device, void *stream, int slot, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     scratch_buf &b = g_scratch[scratch_key{device, stream, slot}];
@@ -62,6 +67,7 @@ void *yk_scratch(int device, void *stream, int slot, size_t bytes) {
         if (b.p) {
             (void)hipStreamSynchronize((hipStream_t)stream);
             (void)hipFree(b.p);
+            ++g_scratch_gen[std::make_pair(device, stream)];
         }
         size_t want = bytes + bytes / 2;
         if (hipMalloc(&b.p, want) != hipSuccess) {
@@ -73,6 +79,27 @@ void *yk_scratch(int device, void *stream, int slot, size_t bytes) {
         b.bytes = want;
     }
     return b.p;
+}
+
+extern "C" unsigned long long yk_scratch_generation(void *stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch_gen.find(std::make_pair(dev, stream));
+    return it == g_scratch_gen.end() ? 0ull : it->second;
+}
+// frees the scratch buffers keyed by a stream that is about to be destroyed (its handle value may be handed out again)
+void yk_scratch_release_stream(void *stream) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+        if (it->first.stream == stream) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = g_scratch.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    for (auto it = g_scratch_gen.begin(); it != g_scratch_gen.end();) it = it->first.second == stream ? g_scratch_gen.erase(it) : std::next(it);
 }
 
 // ------------------------------------------------------------------ kernels

@@ -113,7 +113,7 @@ __device__ __forceinline__ float xp_cluster_barrier(unsigned long long *gran, in
             if (__all((uint32_t)(x >> 32) == ordinal)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) {                               // ~1 s: the members are not co-resident
-                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host memory: the host polls it
                 break;
             }
         }

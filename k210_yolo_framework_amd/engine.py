@@ -70,8 +70,8 @@ def lib() -> C.CDLL:
         L.yk_last_error.restype = C.c_char_p
         L.yk_device_count.restype = C.c_int
         for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
-                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_check', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
-                   'yk_graph_begin', 'yk_graph_end', 'yk_graph_launch', 'yk_graph_node_count', 'yk_graph_kernel_node_count', 'yk_memcpy_async', 'yk_host_device_ptr', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
+                   'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_check', 'yk_plan_peek_error', 'yk_plan_debug_set_error', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
+                   'yk_graph_begin', 'yk_graph_end', 'yk_graph_launch', 'yk_graph_node_count', 'yk_graph_kernel_node_count', 'yk_memcpy_async', 'yk_host_device_ptr', 'yk_stream_create', 'yk_stream_destroy', 'yk_stream_query_priority', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
                    'region_layer_init', 'yk_gemm_f32', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_bwd_f32',
                    'yk_bias_add_f32', 'yk_colsum_f32', 'yk_upsample2x_bwd_f32', 'yk_maxpool2_fwd_f32',
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
             getattr(L, fn).restype = C.c_int
         L.yk_plan_destroy.restype = None
         L.yk_graph_destroy.restype = None
+        L.yk_scratch_generation.restype = C.c_ulonglong
         _lib = L
     return _lib
 
@@ -186,6 +187,16 @@ class Plan:
     def check(self) -> None:
         """Wait for the device; raise if an earlier asynchronous run of this plan failed on the device (yk_plan_check)."""
         _check(lib().yk_plan_check(self._h), 'yk_plan_check')
+
+    def raise_if_failed(self) -> None:
+        """Raise if a run of this plan that has ALREADY finished failed on the device (yk_plan_peek_error: a read of mapped host memory,
+        no synchronisation - call it after waiting for the run's stream or event).  The flag is cleared by the report."""
+        e = C.c_uint()
+        _check(lib().yk_plan_peek_error(self._h, C.c_int(1), C.byref(e)), 'yk_plan_peek_error')
+        if e.value:
+            raise YkError('f16x2 cluster launch: a workgroup cluster did not assemble (its workgroups were not co-resident, e.g. another '
+                          'kernel held CUs for the whole launch); the results of that run are invalid.  Use schedule=\'throughput\' when the '
+                          'GPU is shared.')
 
     def output_ptrs(self) -> List[Tuple[int, Tuple[int, int, int]]]:
         res = []
@@ -406,6 +417,7 @@ class Ticket:
     def result(self):
         self.event.synchronize()
         s = self._slot
+        s.plan.raise_if_failed()
         off = s.h_offsets[:self.batch + 1].numpy().copy()
         n = int(off[-1])
         rows = s.h_rows[:n].numpy().copy()
@@ -436,11 +448,15 @@ class Pipeline:
 
     def __init__(self, spec: ns.NetSpec, weights, anchors, max_batch: int = 32, depth: int = 3, device: Optional[int] = None,
                  precision: str = 'f16x2', graph: bool = True, src_hw: Optional[Tuple[int, int]] = None, max_out: int = 30,
-                 schedule: str = 'auto'):
+                 schedule: str = 'auto', streams: str = 'native'):
         """schedule: 'auto' = 'latency' for depth 1 (one batch at a time: the cluster launches finish it soonest), 'throughput' for
-        depth >= 2 (batches in flight on several streams: the launch-per-layer form overlaps better); see Plan."""
+        depth >= 2 (batches in flight on several streams: the launch-per-layer form overlaps better); see Plan.
+        streams: 'native' = the slots' HIP streams are created by the library, back to back (yk_stream_create): they land on
+        consecutive hardware queues whatever streams the process created before; 'torch' = streams from torch's pool."""
         import torch
         require_gpu()
+        if streams not in ('native', 'torch'):
+            raise YkError(f'streams {streams!r}: expected native or torch')
         self.depth = max(1, int(depth))
         self.schedule = ('latency' if self.depth == 1 else 'throughput') if schedule == 'auto' else schedule
         self.spec, self.max_batch, self.graph = spec, int(max_batch), bool(graph)
@@ -450,7 +466,16 @@ class Pipeline:
         self.outs = [p.outputs() for p in self.plans]
         dev = torch.device(f'cuda:{self.plans[0].device}')
         cur = torch.cuda.current_stream()
-        self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
+        self._own_streams = []
+        if streams == 'native':
+            with torch.cuda.device(dev):
+                for _ in range(self.depth):
+                    h = C.c_void_p()
+                    _check(lib().yk_stream_create(C.byref(h), C.c_int(0)), 'yk_stream_create')
+                    self._own_streams.append(h)
+            self.streams = [torch.cuda.ExternalStream(h.value, device=dev) for h in self._own_streams]
+        else:
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.depth)]
         for s in self.streams:
             s.wait_stream(cur)
         self.cfg = make_decode_cfg(anchors, spec.class_num, spec.in_hw, spec.out_hw())
@@ -461,14 +486,15 @@ class Pipeline:
             s = _Slot()
             s.plan, s.stream, s.st = self.plans[i], self.streams[i], C.c_void_p(self.streams[i].cuda_stream)
             s.preds = (C.c_void_p * len(self.outs[i]))(*[C.c_void_p(o.data_ptr()) for o in self.outs[i]])
-            s.frames = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
-            s.src = torch.empty((B, *self.src_hw, 3), dtype=torch.uint8, device=dev) if self.src_hw else s.frames
+            s.frames = torch.full((B, H, W, 3), 127, dtype=torch.uint8, device=dev)      # (defined bytes: the warm-up step reads them)
+            s.src = torch.full((B, *self.src_hw, 3), 127, dtype=torch.uint8, device=dev) if self.src_hw else s.frames
             s.image_hw = torch.empty((B, 2), dtype=torch.float32, device=dev)
             s.dets = torch.zeros((B, nrow, 6), dtype=torch.float32, device=dev)
             s.counts = torch.zeros((B,), dtype=torch.int32, device=dev)
             s.index = torch.full((B, nrow), -1, dtype=torch.int32, device=dev)
             s.h_src = s.h_rows = s.h_offsets = s.h_index = None                        # pinned side, built on first submit_host
             s.graphs = {}
+            s.scratch_gen, s.warm_dev, s.warm_host = 0, False, False
             s.foreign = []                                                              # caller buffers this slot has captured
             self.slots.append(s)
         self._n = 0
@@ -525,6 +551,13 @@ class Pipeline:
             _check(L.yk_decode_py_ex(C.byref(self.cfg), s.preds, C.c_int(B), ihw, C.c_float(obj), C.c_float(iou), C.c_int(max_out),
                                      _ptr(s.dets), _ptr(s.counts), _ptr(s.index) if want_index else None, s.st), 'yk_decode_py_ex')
 
+    GRAPH_CACHE = 8                     # captured steps kept per slot (one per distinct (batch, source, thresholds, ...) combination)
+
+    def _drop_graphs(self, s):
+        for g in s.graphs.values():
+            g.close()
+        s.graphs.clear()
+
     def _run(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
         if max_out > self.max_out:
             raise YkError(f'max_out {max_out} > the pipeline\'s max_out {self.max_out}')
@@ -533,13 +566,40 @@ class Pipeline:
             self._h2d(s, B)
         if not self.graph:
             return self._issue(s, *args)
-        g = s.graphs.get(args)
+        # a captured step holds the address of the stream's decode scratch: if that buffer has moved since (it cannot once the slot is
+        # warm - __init__ sizes it for max_batch x max_out - but another user of the same stream could grow it), every capture is stale
+        gen = int(lib().yk_scratch_generation(s.st))
+        if gen != s.scratch_gen:
+            s.stream.synchronize()
+            self._drop_graphs(s)
+            s.scratch_gen = gen
+        g = s.graphs.pop(args, None)
         if g is None:
-            if not s.graphs or B > max(k[0] for k in s.graphs):
-                self._issue(s, *args)                              # first use (and every larger batch): eager, sizes the per-stream scratch
+            self._warm(s, host)
+            if len(s.graphs) >= self.GRAPH_CACHE:                  # least recently used first (dicts keep insertion order)
                 s.stream.synchronize()
-            g = s.graphs[args] = capture(s.st, lambda: self._issue(s, *args))
+                s.graphs.pop(next(iter(s.graphs))).close()
+            g = capture(s.st, lambda: self._issue(s, *args))
+        s.graphs[args] = g                                         # (re-)inserted last = most recently used
         g.launch(s.st)
+
+    def _warm(self, s, host):
+        """One eager step at the slot's LARGEST shape (max_batch images, max_out rows per class, box indices on) for each result form the
+        slot uses: sizes the library's per-stream scratch once, so that no later batch size or threshold can make it grow - and move -
+        under a captured step."""
+        B, did = self.max_batch, False
+        if not s.warm_dev:
+            self._issue(s, B, s.src.data_ptr(), False, False, 0.7, 0.5, self.max_out, True)
+            s.warm_dev = did = True
+        if host and not s.warm_host:
+            self._issue(s, B, None, True, False, 0.7, 0.5, self.max_out, True)
+            s.warm_host = did = True
+        if did:
+            s.stream.synchronize()
+            gen = int(lib().yk_scratch_generation(s.st))
+            if gen != s.scratch_gen:                               # the warm-up itself moved a buffer older captures point into
+                self._drop_graphs(s)
+                s.scratch_gen = gen
 
     def _set_hw(self, s, B, image_hw):
         import torch
@@ -613,12 +673,25 @@ class Pipeline:
     def wait(self):
         for s in self.streams:
             s.synchronize()
+        for p in self.plans:
+            p.raise_if_failed()
 
     def close(self):
-        self.wait()
+        for s in self.streams:
+            s.synchronize()
         for s in self.slots:
-            for g in s.graphs.values():
-                g.close()
-            s.graphs = {}
+            self._drop_graphs(s)
         for p in self.plans:
             p.close()
+        self.plans = []
+        self.slots = []
+        self.streams = []
+        for h in self._own_streams:
+            lib().yk_stream_destroy(h)
+        self._own_streams = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

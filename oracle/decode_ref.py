@@ -140,3 +140,27 @@ def decode_batch(preds: Sequence[np.ndarray], anchors, in_hw, image_hw, obj_thre
     ihw = np.broadcast_to(np.asarray(image_hw, F), (B, 2))
     return [decode_image([p[b] for p in preds], anchors, in_hw, ihw[b], obj_thresh, iou_thresh, max_out)
             for b in range(B)]
+
+
+def decode_batch_fast(preds: Sequence[np.ndarray], anchors, in_hw, image_hw, obj_thresh, iou_thresh, max_out=30, threads: int = 1):
+    """decode_batch with the per-class mask + greedy NMS done by oracle/decode_nms_ref.c (the same operations in the same order, held
+    bit-equal to decode_image by tests/test_oracle_decode.py; images in parallel on `threads` OpenMP threads).  The box / score
+    arithmetic stays the numpy code above.  This is what bench.py's cpu_baseline times."""
+    import ctypes as C
+    import oracle
+    L = oracle.lib()
+    B = preds[0].shape[0]
+    ihw = np.broadcast_to(np.asarray(image_hw, F), (B, 2))
+    bs = [decode_boxes_scores([p[b] for p in preds], anchors, in_hw, ihw[b]) for b in range(B)]
+    boxes = np.ascontiguousarray(np.stack([x[0] for x in bs]), F)
+    scores = np.ascontiguousarray(np.stack([x[1] for x in bs]), F)
+    n, nc = scores.shape[1], scores.shape[2]
+    cap = nc * max_out
+    rows = np.zeros((B, cap, 6), F)
+    idx = np.zeros((B, cap), np.int32)
+    counts = np.zeros((B,), np.int32)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.yk_ref_nms_batch(boxes.ctypes.data_as(fp), scores.ctypes.data_as(fp), C.c_int(B), C.c_int(n), C.c_int(nc), C.c_float(obj_thresh),
+                       C.c_float(iou_thresh), C.c_int(max_out), rows.ctypes.data_as(fp), idx.ctypes.data_as(ip), counts.ctypes.data_as(ip),
+                       C.c_int(int(threads)))
+    return [(rows[b, :counts[b]].copy(), idx[b, :counts[b]].astype(np.int64)) for b in range(B)]

@@ -151,3 +151,70 @@ def test_capture_refuses_a_cold_stream():
     st.synchronize()
     g.close()
     plan.close()
+
+
+def test_batch_sizes_small_max_small_replay_correctly():
+    """Captured steps of different batch sizes share the slot's decode scratch: the pipeline sizes it once for max_batch x max_out (a
+    warm-up step at the largest shape) so that a larger batch later cannot move the buffer under a graph captured at a smaller one;
+    should it move anyway (yk_scratch_generation), the slot's graphs are dropped and captured again."""
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    frames = torch.randint(0, 256, (16, 224, 320, 3), dtype=torch.uint8, device='cuda', generator=g)
+    eager = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=16, depth=1, graph=False)
+    want = {}
+    for B in (3, 16):
+        d, c, _ = eager.submit(None if False else frames[:B].contiguous())
+        eager.wait()
+        want[B] = (d.cpu().numpy().copy(), c.cpu().numpy().copy())
+    eager.close()
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=16, depth=1, graph=True)
+    small, big = frames[:3].contiguous(), frames
+    for B, f in ((3, small), (16, big), (3, small), (16, big), (3, small)):
+        gen0 = pipe.slots[0].scratch_gen
+        d, c, _ = pipe.submit(f)
+        pipe.wait()
+        wd, wc = want[B]
+        assert np.array_equal(c.cpu().numpy(), wc), B
+        for b in range(B):
+            assert np.array_equal(d[b, :wc[b]].cpu().numpy(), wd[b, :wc[b]]), (B, b)
+        if gen0:
+            assert pipe.slots[0].scratch_gen == gen0                     # the warm slot's scratch never moves again
+    assert len(pipe.slots[0].graphs) == 2                                # one capture per batch size, both replayed
+    # thresholds are baked into a capture: a sweep captures per value but keeps at most GRAPH_CACHE of them
+    for t in np.linspace(0.3, 0.9, engine.Pipeline.GRAPH_CACHE + 3):
+        pipe.submit(small, obj_thresh=float(t))
+    pipe.wait()
+    assert len(pipe.slots[0].graphs) == engine.Pipeline.GRAPH_CACHE
+    d, c, _ = pipe.submit(small)                                         # evicted or not, the default step still gives the same rows
+    pipe.wait()
+    assert np.array_equal(c.cpu().numpy(), want[3][1])
+    pipe.close()
+
+
+def test_device_side_failure_of_a_cluster_launch_is_raised_where_results_are_consumed():
+    """The latency schedule's cluster launches give up after a bounded spin and set the plan's sticky error word (mapped host memory):
+    Pipeline.wait() / Ticket.result() / Plan.check() raise instead of handing out garbage; the report clears the flag."""
+    import ctypes as C
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=2, depth=1)
+    assert pipe.schedule == 'latency'
+    frames = torch.randint(0, 256, (2, 224, 320, 3), dtype=torch.uint8, device='cuda')
+    pipe.submit(frames)
+    pipe.wait()                                                           # a healthy run: nothing raised
+    e = C.c_uint()
+    engine._check(engine.lib().yk_plan_peek_error(pipe.plans[0]._h, 0, C.byref(e)), 'peek')
+    assert e.value == 0
+    engine._check(engine.lib().yk_plan_debug_set_error(pipe.plans[0]._h, 1), 'set')   # what a timed-out cluster barrier stores
+    with pytest.raises(engine.YkError, match='cluster'):
+        pipe.wait()
+    pipe.wait()                                                           # reported once, then clear
+    engine._check(engine.lib().yk_plan_debug_set_error(pipe.plans[0]._h, 1), 'set')
+    t = pipe.submit_host(frames.cpu().numpy())
+    with pytest.raises(engine.YkError, match='cluster'):
+        t.result()
+    pipe.plans[0].check()
+    pipe.close()

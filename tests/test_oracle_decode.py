@@ -1,5 +1,6 @@
 """Known answers / properties anchoring oracle/decode_ref.py (python-mode decode + TF-1.14 NMS restatement)."""
 import numpy as np
+import pytest
 from hypothesis import given, settings, strategies as st
 
 from oracle import decode_ref as dr
@@ -96,3 +97,25 @@ def test_decode_image_order_and_multiclass_emit():
     for c in np.unique(dets[:, 5]):
         s = dets[dets[:, 5] == c][:, 4]
         assert all(a >= b for a, b in zip(s, s[1:]))
+
+
+@pytest.mark.parametrize('seed,obj,iou', [(0, 0.7, 0.5), (1, 0.3, 0.3), (2, 0.05, 0.6)])
+def test_c_nms_helper_is_bit_equal_to_the_python_restatement(seed, obj, iou):
+    """oracle/decode_nms_ref.c (what bench.py's cpu_baseline times) against decode_ref.decode_batch on seeded logits: the same rows, in
+    the same order, bit for bit, the same box indices - also with ties (quantised logits), cap 30 reached and empty classes."""
+    rng = np.random.default_rng(seed)
+    B, A, Cn = 3, 3, 20
+    preds = []
+    for (h, w) in ((7, 10), (14, 20)):
+        p = rng.normal(0, 2.0, (B, h, w, A, 5 + Cn)).astype(np.float32)
+        p[..., 4] += 1.0
+        if seed == 1:
+            p = np.round(p * 2) / 2                                  # many exactly equal scores: the tie order matters
+        p[..., 5 + 7] = -30.0                                        # a class nobody passes
+        preds.append(p.astype(np.float32))
+    want = dr.decode_batch(preds, ANCHORS, (224, 320), (240, 320), obj, iou)
+    got = dr.decode_batch_fast(preds, ANCHORS, (224, 320), (240, 320), obj, iou, threads=2)
+    assert sum(len(w_[0]) for w_ in want) > 100
+    for (wr, wi), (gr, gi) in zip(want, got):
+        assert wr.shape == gr.shape and np.array_equal(wr.view(np.uint32), gr.view(np.uint32))
+        assert np.array_equal(wi, gi)

@@ -67,3 +67,30 @@ def test_shard_indices_partition_properties():
         shard.merge_by_image(3, [np.array([0, 1])], [['a', 'b']])
     with pytest.raises(ValueError):
         shard.merge_by_image(2, [np.array([0, 0])], [['a', 'b']])
+
+
+def test_numa_binding_reads_sysfs_and_binds_to_the_gpus_node(tmp_path):
+    """shard.bind_to_gpu_numa against a fake sysfs tree: the node of the GPU's PCI function, that node's cpulist intersected with the
+    CPUs this process may use; unknown node (-1) or missing files change nothing (host feeding bounds the N-GPU curve)."""
+    import os
+    from k210_yolo_framework_amd import shard
+    assert shard.parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    have = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / 'bus' / 'pci' / 'devices' / '0000:c1:00.0'
+    dev.mkdir(parents=True)
+    (dev / 'numa_node').write_text('1\n')
+    nd = tmp_path / 'devices' / 'system' / 'node' / 'node1'
+    nd.mkdir(parents=True)
+    (nd / 'cpulist').write_text(f'{have[0]},900-903\n')
+    info = shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:C1:00.0', apply=False)
+    assert info == {'pci': '0000:C1:00.0', 'node': 1, 'cpus': 1}
+    before = os.sched_getaffinity(0)
+    try:
+        info = shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')
+        assert info['cpus'] == 1 and os.sched_getaffinity(0) == {have[0]}
+    finally:
+        os.sched_setaffinity(0, before)
+    (dev / 'numa_node').write_text('-1\n')
+    assert shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')['cpus'] is None
+    assert shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:ff:00.0')['node'] == -1
+    assert os.sched_getaffinity(0) == before
