@@ -809,7 +809,10 @@ static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
     {128, 64, 32, "igemm_128x64"}, {128, 48, 32, "igemm_128x48"}, {128, 96, 32, "igemm_128x96"},
     {128, 192, 64, "igemm_128x192k64"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 64, "igemm_128x128k64"},
     {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}, {128, 64, 64, "igemm_128x64k64"},
-    {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}, {256, 128, 64, "igemm_256x128k64"}};
+    {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}, {256, 128, 64, "igemm_256x128k64"},
+    {256, 128, 64, "igemm_256x128k64w4"}, {128, 256, 64, "igemm_128x256k64"}, {128, 128, 64, "igemm_128x128k64r"}, {256, 256, 64, "igemm_256x256k64"}};
+
+static int yk_big_ring_depth(int cfg) { return cfg == IGEMM_256x128 ? 3 : 2; }
 
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     switch (cfg) {
@@ -824,15 +827,22 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     case IGEMM_128x64K64: return launch_cfg<128, 64, 2, 2, 64, false, true>(a, st);
     case IGEMM_64x128: return launch_cfg<64, 128, 2, 2, 64, false, true>(a, st);
     case IGEMM_64x192: return launch_cfg<64, 192, 2, 2, 64, false, true>(a, st);
-#ifdef YK_DEV
-    // next step of DESIGN.md 8(1): the ring kernel on EIGHT waves (4 x 2, 64x64 per wave) - the waves per CU of the 64x128 tile with half
-    // its operand stream.  Never picked; reachable with YK_IGEMM_FORCE in the developer build, LDS-DMA preconditions only.
-    case IGEMM_256x128: {
+    // large ring tiles (MFMA-bound layers at large M: Darknet-53 / tiny-YOLO 3x3 convs); LDS-DMA preconditions only, no register-staged fallback
+    case IGEMM_256x128:
+    case IGEMM_256x128W4:
+    case IGEMM_128x256:
+    case IGEMM_128x128R:
+    case IGEMM_256x256: {
         const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
         if ((a.c0p + a.c1p) % 64 || a.c0p % 64 || (uint64_t)a.in0_bytes + margin >= YK_OOB || (uint64_t)a.in1_bytes + margin >= YK_OOB) break;
-        return launch_pipe<256, 128, 4, 2, 2>(a, st);
+        const int ns_env = yk_dev_env("YK_NS") ? atoi(yk_dev_env("YK_NS")) : 0;     // (developer build: read per launch, tools/r05_igemm_sweep.py)
+        const int ns = ns_env ? ns_env : yk_big_ring_depth(cfg);
+        if (cfg == IGEMM_256x128) return ns >= 3 ? launch_pipe<256, 128, 4, 2, 3>(a, st) : launch_pipe<256, 128, 4, 2, 2>(a, st);
+        if (cfg == IGEMM_256x128W4) return ns >= 3 ? launch_pipe<256, 128, 2, 2, 3>(a, st) : launch_pipe<256, 128, 2, 2, 2>(a, st);
+        if (cfg == IGEMM_256x256) return launch_pipe<256, 256, 4, 2, 2>(a, st);
+        if (cfg == IGEMM_128x256) return ns >= 3 ? launch_pipe<128, 256, 2, 2, 3>(a, st) : launch_pipe<128, 256, 2, 2, 2>(a, st);
+        return ns >= 4 ? launch_pipe<128, 128, 2, 2, 4>(a, st) : (ns == 3 ? launch_pipe<128, 128, 2, 2, 3>(a, st) : launch_pipe<128, 128, 2, 2, 2>(a, st));
     }
-#endif
     }
     yk_set_error("yk_launch_igemm: bad config %d", cfg);
     return YK_ERR_ARG;
@@ -851,7 +861,7 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
         const char *f = yk_dev_env("YK_IGEMM_FORCE");
         if (f && f[0]) {
             const int c = atoi(f);
-            const bool ring_only = c == IGEMM_256x128;                 // has no register-staged fallback: only where the LDS-DMA ring applies
+            const bool ring_only = c >= IGEMM_256x128;                 // no register-staged fallback: only where the LDS-DMA ring applies
             const bool ring_ok = ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);
             if (c >= 0 && c < IGEMM_NUM && c != IGEMM_F32_64x80 && c != IGEMM_F32_128x64 && a.N % g_cfg[c].bn == 0 && (!ring_only || ring_ok))
                 return c;
@@ -869,6 +879,14 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     // with LDS-DMA tiles the 64x128x64 config is the fastest wherever it applies (52x52 128->256: 519 vs 460 TFLOP/s for 64x64x64,
     // 13x13 512->1024: 480 vs 447); the register-staged fallbacks (upsampled input, channel pitch not a multiple of 64) keep 64x64
     const bool dma_ok = ((a.c0p + a.c1p) % 64 == 0) && (a.c0p % 64 == 0);     // upsampled sources included (yk_igemm_pipe.h)
+    // round 5, tools/r05_igemm_sweep.py at 32 / 64 images: from ~150 k GEMM rows on the 128x128 ring tile (two stages, two workgroups per CU)
+    // is 5-8 % ahead on the 3x3 layers (52x52 128->256 at 64 images: 718 vs 663 TFLOP/s) and 17-22 % on the wide 1x1 layers
+    // (52x52 256->128: 308 vs 263); below that the two tie and the smaller tile fills the chip better
+    {
+        const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
+        const bool ring_fits = (uint64_t)a.in0_bytes + margin < YK_OOB && (uint64_t)a.in1_bytes + margin < YK_OOB;   // (the ring kernel has no fallback form)
+        if (dma_ok && ring_fits && !a.up0 && a.N % 128 == 0 && a.M >= 150000 && a.K >= 256) return IGEMM_128x128R;
+    }
     if (a.K >= 512) return (a.N % 128 == 0 && dma_ok) ? IGEMM_64x128 : IGEMM_64x64;
     if (mt128 * ((a.N + 63) / 64) >= 256) return IGEMM_128x64;
     return IGEMM_64x64;

@@ -309,7 +309,8 @@ __device__ __forceinline__ void x_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PART>
+// IL (round 5): the prefetch step's DMA pieces go out BETWEEN the MFMAs of the step being computed (yk_igemm_pipe.h has the measurement)
+template <int BM, int BN, int WM, int WN, int NS, bool PART, bool IL = false>
 __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     typedef xg_cfg<BM, BN, WM, WN> C;
     constexpr int NW = C::NW, TM = C::TM, TN = C::TN;
@@ -407,33 +408,33 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
     };
     retap();
     const uint32_t wbase = (uint32_t)(n0 >> 4) * 2048u + (uint32_t)(wid * B_IT) * 1024u + lane * 16u, wstep = (uint32_t)a.nslab * 2048u;
-    auto dma = [&](int stage) {
+    // one step's DMA = prepare (uniform offsets) + A_IT + B_IT pieces + advance (walk state)
+    uint32_t d_cso = 0, d_ws = 0;
+    auto dma_prepare = [&]() {
         const bool live = step < lim;
         const int nc = seg ? a.nc1 : a.nc0;
         const bool bad = !live || (cs == nc - 1 && (seg ? lastbad1 : lastbad0));
-        const uint32_t cso = bad ? X_OOB : (uint32_t)cs * 128u;
+        d_cso = bad ? X_OOB : (uint32_t)cs * 128u;
+        d_ws = live ? wbase + (uint32_t)step * wstep : X_OOB;
+    };
+    auto dma_piece = [&](int stage, int n) {                       // n: a compile-time constant after unrolling
         unsigned char *As = xsm + stage * C::STAGE, *Bs = As + BM * 128;
-        if (seg) {
-#pragma unroll
-            for (int it = 0; it < AR; ++it) {
-                const uint32_t o0 = aoff[it] + cso, o1 = o0 + 16u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(As + (wid * A_IT + it * 2) * 1024), 16, o0, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(As + (wid * A_IT + it * 2 + 1) * 1024), 16, o1, 0, 0, 0);
+        if (n < A_IT) {
+            const uint32_t o = aoff[(n >> 1) < AR ? (n >> 1) : 0] + d_cso + (uint32_t)(n & 1) * 16u;
+            lds_ptr_t dsta = (lds_ptr_t)(As + (wid * A_IT + n) * 1024);
+            if (seg) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dsta, 16, o, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dsta, 16, o, 0, 0, 0);
             }
         } else {
-#pragma unroll
-            for (int it = 0; it < AR; ++it) {
-                const uint32_t o0 = aoff[it] + cso, o1 = o0 + 16u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(As + (wid * A_IT + it * 2) * 1024), 16, o0, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(As + (wid * A_IT + it * 2 + 1) * 1024), 16, o1, 0, 0, 0);
-            }
+            const int it = n - A_IT;
+            const uint32_t ob = d_ws + (uint32_t)it * 1024u;
+            lds_ptr_t dstb = (lds_ptr_t)(Bs + (wid * B_IT + it) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, ob, 0, 0, 0);
         }
-        const uint32_t ws = live ? wbase + (uint32_t)step * wstep : X_OOB;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const uint32_t ob = ws + (uint32_t)it * 1024u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Bs + (wid * B_IT + it) * 1024), 16, ob, 0, 0, 0);
-        }
+    };
+    auto dma_advance = [&]() {
         ++step;
         ++tap;
         if (tap >= a.taps) {                                       // uniform
@@ -445,6 +446,14 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
             }
         }
         if (a.taps > 1 || cs == 0) retap();                        // 1x1: the row offsets only change with the segment
+    };
+    auto dma = [&](int stage) {
+        dma_prepare();
+#pragma unroll
+        for (int n = 0; n < L; ++n) {
+            dma_piece(stage, n);
+        }
+        dma_advance();
     };
     floatx4 acc[TM][TN];
 #pragma unroll
@@ -480,6 +489,45 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
     };
+    // the same step with the prefetch step's pieces spread over its 3 * TM * TN MFMAs
+    auto compute_il = [&](int stage, int wstage) {
+        constexpr int NM = 3 * TM * TN;
+        const unsigned char *As = xsm + stage * C::STAGE, *Bs = As + BM * 128;
+        dma_prepare();
+        half8 xh[TM], xl[TM], wh[TN], wl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            xh[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 2) * 1024 + foff);
+            xl[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 2 + 1) * 1024 + foff);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            wh[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 2) * 1024 + foff);
+            wl[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 2 + 1) * 1024 + foff);
+        }
+#pragma unroll
+        for (int sw = 0; sw < 3; ++sw)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (sw == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+                    else if (sw == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+                    const int idx = (sw * TM + i) * TN + j;
+                    const int p0 = idx * L / NM, p1 = (idx + 1) * L / NM;          // pieces [p0, p1) go out behind this MFMA
+                    if (p1 > p0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pp = 0; pp < (L + NM - 1) / NM + 1; ++pp)
+                            if (p0 + pp < p1) {
+                                dma_piece(wstage, p0 + pp);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        dma_advance();
+    };
     // image of each accumulator row (relative to b0)
     int rowb[TM];
 #pragma unroll
@@ -506,8 +554,12 @@ __global__ void __launch_bounds__(64 * WM * WN) xg_kernel(const xg_args a) {
             rescale();
             in0 = false;
         }
-        dma(wr);
-        if (!X_DBG(a, 16)) compute(rd);
+        if constexpr (IL) {
+            compute_il(rd, wr);
+        } else {
+            dma(wr);
+            if (!X_DBG(a, 16)) compute(rd);
+        }
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
@@ -989,6 +1041,17 @@ struct xlaunch {
     double flops = 0, bytes = 0;
 };
 
+// interleaved DMA issue (IL): measured no faster (K2 step 646.6 vs 637.4 us of kernels, Darknet-53 f16x2 3119 vs 3089 images/s; gpurun_out/r5c3):
+// a wave blocks on the vector-memory issue of a piece wherever the piece sits in its stream - off unless YK_X_IL=1
+static bool x_interleave() {
+#ifdef YK_DEV
+    const char *e = getenv("YK_X_IL");
+    return e && e[0] == '1';
+#else
+    static const bool on = yk_env_flag("YK_X_IL", false);
+    return on;
+#endif
+}
 template <int BM, int BN, int WM, int WN, int NS>
 int x_launch_g(const xg_args &g, hipStream_t st) {
     typedef xg_cfg<BM, BN, WM, WN> C;
@@ -997,23 +1060,24 @@ int x_launch_g(const xg_args &g, hipStream_t st) {
     auto allow = [&](const void *k, unsigned bytes) {
         if (bytes > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     };
+    const bool il = x_interleave();
+    static bool once = false;
+    if (!once) {
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true, false>), lds);
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true, true>), lds);
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false, false>), lds);
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false, true>), lds);
+        allow(reinterpret_cast<const void *>(xg_reduce_kernel<BM, BN, WM, WN>), rlds);
+        once = true;
+    }
     if (g.splitk > 1) {
-        static bool once = false;
-        if (!once) {
-            allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true>), lds);
-            allow(reinterpret_cast<const void *>(xg_reduce_kernel<BM, BN, WM, WN>), rlds);
-            once = true;
-        }
-        hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true>), grid, dim3(C::NT), lds, st, g);
+        if (il) hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, true>), grid, dim3(C::NT), lds, st, g);
+        else hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, false>), grid, dim3(C::NT), lds, st, g);
         grid.z = 1;
         hipLaunchKernelGGL((xg_reduce_kernel<BM, BN, WM, WN>), grid, dim3(C::NT), rlds, st, g);
     } else {
-        static bool once = false;
-        if (!once) {
-            allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false>), lds);
-            once = true;
-        }
-        hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false>), grid, dim3(C::NT), lds, st, g);
+        if (il) hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, true>), grid, dim3(C::NT), lds, st, g);
+        else hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, false>), grid, dim3(C::NT), lds, st, g);
     }
     return YK_OK;
 }

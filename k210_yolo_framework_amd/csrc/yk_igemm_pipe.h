@@ -25,7 +25,16 @@ __device__ __forceinline__ void yk_wait_vm_lgkm0() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int OUT, bool UP>
+// IL (round 5): the DMA pieces of the step being prefetched are issued BETWEEN the MFMAs of the step being computed, one piece per few MFMAs
+// (an LDS-DMA instruction costs its wave ~150 cycles of issue when a whole step's pieces go out in one block ahead of the fragment reads,
+// ~60 in the shadow of the matrix pipe - MI355X_MICROARCH.md "LDS-DMA piece issue cost"; tools/r05_igemm_sweep.py: without it every tile
+// shape from 64x128 to 256x128 sits at 550-700 TFLOP/s at B=32, i.e. the loop is bound by DMA issue, not by the tile).
+// PS (round 5, phase split): half of the waves of a SIMD issue the step's DMA pieces BEFORE their MFMAs, the other half AFTER (needs NS >= 3:
+// a piece issued at the end of step k is waited for at the start of step k + 2).  A barrier releases every wave at once; unsplit, all of them
+// then sit in the vector-memory issue queue together (~100 cycles per 1 KB piece, the matrix pipe idle) and afterwards compete for the matrix
+// pipe together (tools/r05_igemm_phase.py: 870 cycles of DMA issue + 1450 of MFMAs + 1200 at the barrier per k-step for 1024 cycles of MFMA).
+// PS 1: by wave index (8-wave workgroups: waves w and w + 4 share a SIMD); PS 2: by the hardware wave slot's parity (two 4-wave workgroups per CU).
+template <int BM, int BN, int WM, int WN, int NS, int OUT, bool UP, bool IL = false, int PS = 0>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_args a) {
     constexpr int NW = WM * WN, BK = 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -110,30 +119,34 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
         }
     };
     retap();
-    auto dma = [&](int stage) {
+    // one step's DMA = prepare (uniform offsets) + A_IT + B_IT pieces + advance (walk state)
+    uint32_t d_cs = 0, d_ws = 0;
+    bool d_second = false;
+    auto dma_prepare = [&]() {
         const bool live = step < lim;
-        const uint32_t cs = live ? (uint32_t)cin * 2u : YK_OOB;                  // dead steps (past the split's end) deposit zeros
-        const uint32_t ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
+        d_cs = live ? (uint32_t)cin * 2u : YK_OOB;                                 // dead steps (past the split's end) deposit zeros
+        d_ws = live ? (uint32_t)step * (BK * 2u) : YK_OOB;
+        d_second = cin >= a.c0p;
+    };
+    auto dma_piece = [&](int stage, int n) {                                      // n: a compile-time constant after unrolling
         yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
-        if (cin >= a.c0p) {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const uint32_t off = aoff1[it] + cs;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(As + (wid + it * NW) * 8 * BK), 16, off, 0, 0, 0);
+        if (n < A_IT) {
+            lds_ptr_t dsta = (lds_ptr_t)(As + (wid + n * NW) * 8 * BK);
+            if (d_second) {
+                const uint32_t off = aoff1[n < A_IT ? n : 0] + d_cs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dsta, 16, off, 0, 0, 0);
+            } else {
+                const uint32_t off = aoff0[n < A_IT ? n : 0] + d_cs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dsta, 16, off, 0, 0, 0);
             }
         } else {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const uint32_t off = aoff0[it] + cs;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(As + (wid + it * NW) * 8 * BK), 16, off, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
+            const int it = n - A_IT;
             lds_ptr_t dstb = (lds_ptr_t)(Bs + (wid + it * NW) * 8 * BK);
-            const uint32_t offb = wro[it] + ws;     // a named local: with the sum written inline hipcc's HOST pass silently drops
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, offb, 0, 0, 0);   // the kernel's stub (undefined symbol at load)
+            const uint32_t offb = wro[it < B_IT ? (it < 0 ? 0 : it) : 0] + d_ws;     // a named local (see the host-pass note in yk_igemm_pipe.h's first version)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dstb, 16, offb, 0, 0, 0);
         }
+    };
+    auto dma_advance = [&]() {
         ++step;
         cin += BK;
         if (cin >= Ctp) {                                                         // uniform, every Ctp/64 steps
@@ -141,6 +154,14 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
             ++tap;
             retap();
         }
+    };
+    auto dma = [&](int stage) {
+        dma_prepare();
+#pragma unroll
+        for (int n = 0; n < L; ++n) {
+            dma_piece(stage, n);
+        }
+        dma_advance();
     };
     floatx4 acc[TM][TN];
 #pragma unroll
@@ -164,24 +185,145 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
     };
+    // IL: the software-pipelined step (round 5).  Counters of the plain loop on a Darknet 52x52 128->256 3x3 at 32 images (profiles/r05_igemm_pmc.txt):
+    // matrix pipe busy 0.28, waves 34-40 % parked at s_waitcnt / s_barrier, 2600 cycles per wave and k-step for 512 cycles of MFMA - a wave's
+    // step was a serial chain  barrier -> 8 fragment reads (~250 cycles exposed) -> 16 MFMAs -> 8 reads -> 16 MFMAs, with the step's DMA pieces
+    // issued in one block in front.  Here the two half-steps' fragments live in two register sets: the reads of the second half go out before
+    // the first half's MFMAs, the reads of the NEXT step's first half right behind the barrier that ends this step (under the tail of its
+    // MFMAs), and the prefetch step's DMA pieces are spread between the MFMAs, one per NM / L of them.
+    half8 wf0[TN], xf0[TM], wf1[TN], xf1[TM];
+    auto read_frags = [&](int stage, int ks, half8 (&wf)[TN], half8 (&xf)[TM]) {
+        const yk_half *As = lds + stage * STAGE, *Bs = As + BM * BK;
+        const int ch = ((ks * 4 + fq) ^ sw) * 8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8 *>(Bs + ((wn * TN + j) * 16 + fr) * BK + ch);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8 *>(As + ((wm * TM + i) * 16 + fr) * BK + ch);
+    };
+    auto mma_half = [&](int ks, const half8 (&wf)[TN], const half8 (&xf)[TM], int wstage) {
+        constexpr int NM = 2 * TM * TN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                const int idx = (ks * TM + i) * TN + j;                           // MFMA number inside the step
+                const int p0 = idx * L / NM, p1 = (idx + 1) * L / NM;             // pieces [p0, p1) go out here
+                if (p1 > p0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pp = 0; pp < (L + NM - 1) / NM + 1; ++pp)
+                        if (p0 + pp < p1) {
+                            dma_piece(wstage, p0 + pp);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    };
+#ifdef YK_DEV
+    // developer build: where a wave's loop time goes (cycles of wave 0, summed over the k-steps) -> a.dbg[workgroup][8] (tools/r05_igemm_phase.py)
+    long long c_wait = 0, c_bar = 0, c_dma = 0, c_mma = 0, c_t = 0;
+    const long long wall0 = a.dbg ? (long long)wall_clock64() : 0;
+#define PIPE_CLK(v) if (a.dbg) { const long long n_ = (long long)__builtin_readcyclecounter(); v += n_ - c_t; c_t = n_; }
+#define PIPE_CLK0() if (a.dbg) c_t = (long long)__builtin_readcyclecounter();
+#else
+#define PIPE_CLK(v)
+#define PIPE_CLK0()
+#endif
+    static_assert(PS == 0 || NS >= 3, "a late DMA needs a step of slack");
+    bool late_dma = false;
+    if constexpr (PS == 1) late_dma = wid >= NW / 2;
+    if constexpr (PS == 2) late_dma = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;    // hwreg(HW_REG_HW_ID, 0, 4): wave slot inside its SIMD
     if (nk > 0) {
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s) dma(s);                   // steps past `lim` deposit zeros and keep the vmcnt arithmetic uniform
         int rd = 0, wr = NS - 1;                                   // stage read this step / stage refilled this step
-        for (int kt = 0; kt < nk; ++kt) {
+        PIPE_CLK0()
+        if constexpr (IL) {
             yk_wait_vm_lgkm0<(NS - 2) * L>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            dma(wr);
-            compute(rd);
-            rd = (rd + 1 == NS) ? 0 : rd + 1;
-            wr = (wr + 1 == NS) ? 0 : wr + 1;
+            read_frags(0, 0, wf0, xf0);
+            for (int kt = 0; kt < nk; ++kt) {
+                dma_prepare();
+                read_frags(rd, 1, wf1, xf1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half(0, wf0, xf0, wr);
+                mma_half(1, wf1, xf1, wr);
+                dma_advance();
+                rd = (rd + 1 == NS) ? 0 : rd + 1;
+                wr = (wr + 1 == NS) ? 0 : wr + 1;
+                PIPE_CLK(c_mma)
+                yk_wait_vm_lgkm0<(NS - 2) * L>();                  // the next step's pieces have landed (this wave's) ...
+                PIPE_CLK(c_wait)
+                __builtin_amdgcn_s_barrier();                      // ... everybody's have, and everybody has read the stage refilled next
+                asm volatile("" ::: "memory");
+                PIPE_CLK(c_bar)
+                read_frags(rd, 0, wf0, xf0);                       // under the tail of this step's MFMAs (after the last step: a dead stage)
+            }
+            yk_wait_vm_lgkm0<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                yk_wait_vm_lgkm0<(NS - 2) * L>();
+                PIPE_CLK(c_wait)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                PIPE_CLK(c_bar)
+                if (PS != 0 && late_dma) {
+                    compute(rd);
+                    PIPE_CLK(c_mma)
+                    dma(wr);
+                    PIPE_CLK(c_dma)
+                } else {
+                    dma(wr);
+                    PIPE_CLK(c_dma)
+                    compute(rd);
+                }
+                rd = (rd + 1 == NS) ? 0 : rd + 1;
+                wr = (wr + 1 == NS) ? 0 : wr + 1;
+                PIPE_CLK(c_mma)
+            }
+            yk_wait_vm_lgkm0<0>();                                 // drain the dead prefetches before LDS is reused by the epilogue
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        yk_wait_vm_lgkm0<0>();                                     // drain the dead prefetches before LDS is reused by the epilogue
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
+#ifdef YK_DEV
+    const long long wall1 = a.dbg ? (long long)wall_clock64() : 0;
+#endif
     igemm_epilogue<BM, BN, WM, WN, OUT, TM, TN>(a, acc, lds, m0, n0, tid, lane, wm, wn, vz);
+#ifdef YK_DEV
+    if (a.dbg && tid == 0) {
+        long long *d = a.dbg + (size_t)L0 * 8;
+        d[0] = wall0; d[1] = c_wait; d[2] = c_bar; d[3] = c_dma; d[4] = c_mma; d[5] = wall1; d[6] = (long long)wall_clock64(); d[7] = nk;
+    }
+#endif
+#undef PIPE_CLK
+#undef PIPE_CLK0
+}
+
+// software-pipelined loop (IL): measured no faster than the plain loop (gpurun_out/r5c5: 7001 vs 7285 images/s on Darknet-53) - off unless YK_PIPE_IL=1
+static bool yk_pipe_interleave() {
+#ifdef YK_DEV
+    const char *e = getenv("YK_PIPE_IL");
+    return e && e[0] == '1';
+#else
+    static const bool on = yk_env_flag("YK_PIPE_IL", false);
+    return on;
+#endif
+}
+
+// phase split (PS): off unless YK_PIPE_PS=1
+static int yk_pipe_phase_split() {
+#ifdef YK_DEV
+    const char *e = getenv("YK_PIPE_PS");
+    return (e && e[0] != '0') ? 1 : 0;
+#else
+    static const int on = yk_env_flag("YK_PIPE_PS", false) ? 1 : 0;
+    return on;
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -199,9 +341,24 @@ static int launch_pipe(const igemm_args &a, hipStream_t st) {
         }
         hipLaunchKernelGGL(kern, g2, dim3(64 * WM * WN), ldsd, st, a);
     };
+    const bool il = yk_pipe_interleave();
+    const int ps = NS >= 3 ? yk_pipe_phase_split() : 0;
     if (a.up0) {
         if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, true>);
         else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, true>);
+    } else if (ps && NS >= 3) {
+        if constexpr (NS >= 3) {
+            if (WM * WN >= 8) {
+                if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false, false, 1>);
+                else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false, false, 1>);
+            } else {
+                if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false, false, 2>);
+                else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false, false, 2>);
+            }
+        }
+    } else if (il) {
+        if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false, true>);
+        else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false, true>);
     } else {
         if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false>);
         else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false>);

@@ -80,6 +80,13 @@ class Trainer:
         # captured as a HIP graph and replayed (same kernels, same order, same buffers -> bitwise the same results; measured 7.8 ->
         # 6.7 ms per step for yolo_mobilev2-1.0 at 16 images).  Adam stays outside: its step counter is a launch argument.
         self.use_graph = bool(use_graph)
+        # weight gradients (and the regulariser's dot products) depend on nothing the backward chain waits for: they are issued on a second
+        # stream - inside a captured step a parallel branch of the graph - and joined before the exchange / update (~170 of the step's ~700
+        # launches leave the critical path).  MEASURED (round 5, gpurun_out/r5c3): 5.59 -> 10.37 ms per replayed step - a hipGraph with ~120
+        # cross-stream edges replays at roughly two launch boundaries per edge on this runtime - so it is OFF; YK_TRAIN_WSTREAM=1 turns it on.
+        import os as _os
+        self.wgrad_stream = _os.environ.get('YK_TRAIN_WSTREAM', '0') != '0'
+        self._ws = None
         self._graph = None
         self._gx = self._gy = self._gres = self._side = None
         self._eager_steps = 0
@@ -233,11 +240,34 @@ class Trainer:
         return [T[o].view(self.B, *self.spec.tensors[o][:2], self.spec.anchor_num, e) for o in self.spec.outputs]
 
     # ------------------------------------------------------------------ backward
+    def _wstream(self):
+        """The weight-gradient stream (created once; its split-K / reduction scratch is keyed by the stream, so it never collides with the
+        main chain's)."""
+        if self._ws is None:
+            self._ws = self.torch.cuda.Stream(device=self.dev)
+        return self._ws
+
     def backward(self, out_grads: Sequence["torch.Tensor"]) -> None:
         """out_grads[i] = dL/d(output i).  Fills self.G (kernel/bias/gamma/beta gradients; regulariser added by step())."""
         torch = self.torch
         self.G.zero_()
         D: Dict[int, "torch.Tensor"] = {}
+        main = torch.cuda.current_stream()
+        ws = self._wstream() if self.wgrad_stream else None
+        keep = []                                                   # operands the side stream reads: alive until the join below
+        if ws is not None:
+            ws.wait_stream(main)                                    # G is zero, the forward tape is complete
+
+        def on_side(fn, *tensors):
+            """Run fn() - launches that only WRITE weight gradients - behind everything issued on the main stream so far."""
+            if ws is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            ws.wait_event(ev)
+            with torch.cuda.stream(ws):
+                fn()
+            keep.extend(tensors)
 
         def acc(tid, g, own):
             if tid == 0:
@@ -275,13 +305,14 @@ class Trainer:
                 else:
                     dz = dy
                     if l.use_bias:
-                        self._ck(self.L.yk_colsum_f32(engine._ptr(dz), C.c_longlong(M), C.c_int(co),
-                                                      engine._ptr(self.view(self.G, l.name + '/bias')), self._s()), 'yk_colsum_f32')
+                        gb = self.view(self.G, l.name + '/bias')
+                        on_side(lambda dz=dz, gb=gb: self._ck(self.L.yk_colsum_f32(engine._ptr(dz), C.c_longlong(M), C.c_int(co), engine._ptr(gb),
+                                                                                    self._s()), 'yk_colsum_f32'), dz)
                 need_dx = op['in0'] != 0
                 if t == ns.OP_CONV:
                     k = op['k']
                     if k == 1 and op['stride'] == 1:
-                        self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci)               # dW = dZ^T * X
+                        on_side(lambda dz=dz, x=x, gw=gw: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
                         if need_dx:
                             dx = self._new(self.B, hi, wi, ci)
                             self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)           # dX = dZ * W
@@ -290,7 +321,7 @@ class Trainer:
                         kk = 9 * ci
                         col = self._new(M, kk)
                         self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(col), self._s()), 'yk_im2col3x3_f32')
-                        self.gemm(1, 0, co, kk, M, dz, co, col, kk, gw, kk)
+                        self.gemm(1, 0, co, kk, M, dz, co, col, kk, gw, kk)            # (main stream: `col` is overwritten right below)
                         if need_dx:
                             self.gemm(0, 0, M, kk, co, dz, co, w, kk, col, kk)          # dcol (reuses the buffer)
                             dx = self._new(self.B, hi, wi, ci)
@@ -299,8 +330,9 @@ class Trainer:
                             acc(op['in0'], dx, True)
                         del col
                 else:
-                    self._ck(self.L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dz), *self._geom(op), engine._ptr(gw), self._s()),
-                             'yk_dw3x3_bwd_weight_f32')
+                    geom = self._geom(op)
+                    on_side(lambda x=x, dz=dz, gw=gw, geom=geom: self._ck(self.L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dz), *geom, engine._ptr(gw),
+                                                                                                          self._s()), 'yk_dw3x3_bwd_weight_f32'), dz)
                     if need_dx:
                         dx = self._new(self.B, hi, wi, ci)
                         self._ck(self.L.yk_dw3x3_bwd_data_f32(engine._ptr(dz), engine._ptr(w), *self._geom(op), engine._ptr(dx), self._s()),
@@ -324,24 +356,36 @@ class Trainer:
             elif t == ns.OP_ADD:
                 acc(op['in0'], dy, False)
                 acc(op['in1'], dy, True)
+        if ws is not None:
+            main.wait_stream(ws)                                    # every weight gradient is in G
+        del keep
 
     # ------------------------------------------------------------------ one optimisation step
-    def regulariser(self, add_grad: bool) -> "torch.Tensor":
-        """sum over DarknetConv2D kernels of 5e-4 * sum(w^2) (device scalar); optionally G += 2*5e-4*W."""
-        tot = self.torch.zeros(1, dtype=self.torch.float32, device=self.dev)
+    def regulariser(self, add_grad: bool, value: bool = True) -> "torch.Tensor":
+        """sum over DarknetConv2D kernels of 5e-4 * sum(w^2) (device scalar; value=False skips it); optionally G += 2*5e-4*W."""
+        tot = self.torch.zeros(1, dtype=self.torch.float32, device=self.dev) if value else None
         for l in self.spec.layers:
             if l.kind == 'conv' and _is_darknet_conv(l.name):
                 w = self.view(self.P, l.name + '/kernel')
                 n = w.numel()
-                self._ck(self.L.yk_dot_f32(C.c_longlong(n), engine._ptr(w), engine._ptr(w), C.c_float(L2_WEIGHT), C.c_float(1.0),
-                                           engine._ptr(tot), self._s()), 'yk_dot_f32')                    # tot += 5e-4 * <w, w>
+                if value:
+                    self._ck(self.L.yk_dot_f32(C.c_longlong(n), engine._ptr(w), engine._ptr(w), C.c_float(L2_WEIGHT), C.c_float(1.0),
+                                               engine._ptr(tot), self._s()), 'yk_dot_f32')                # tot += 5e-4 * <w, w>
                 if add_grad:
                     self._axpy(2.0 * L2_WEIGHT, w, self.view(self.G, l.name + '/kernel'))
         return tot
 
     def loss_and_grads(self, x_nhwc, y_true: Sequence["torch.Tensor"]):
         """forward + loss + backward (no all-reduce, no update).  -> dict of device scalars."""
+        torch = self.torch
         global_batch = self.B * self.world
+        reg = None
+        if self.wgrad_stream:
+            # the regulariser's value reads the weights only: its ~35 small launches run beside the forward pass (joined by backward())
+            main, ws = torch.cuda.current_stream(), self._wstream()
+            ws.wait_stream(main)
+            with torch.cuda.stream(ws):
+                reg = self.regulariser(add_grad=False)
         preds = self.forward(x_nhwc)
         parts, grads = [], []
         for li, (yp, yt) in enumerate(zip(preds, y_true)):
@@ -350,7 +394,10 @@ class Trainer:
             parts.append(loss6)
             grads.append(g)
         self.backward(grads)
-        reg = self.regulariser(add_grad=self.world == 1)
+        if reg is None:
+            reg = self.regulariser(add_grad=self.world == 1)
+        elif self.world == 1:
+            self.regulariser(add_grad=True, value=False)
         return dict(layers=parts, reg=reg)
 
     def invalidate_graph(self) -> None:
