@@ -80,12 +80,14 @@ class Trainer:
         # captured as a HIP graph and replayed (same kernels, same order, same buffers -> bitwise the same results; measured 7.8 ->
         # 6.7 ms per step for yolo_mobilev2-1.0 at 16 images).  Adam stays outside: its step counter is a launch argument.
         self.use_graph = bool(use_graph)
-        # weight gradients (and the regulariser's dot products) depend on nothing the backward chain waits for: they are issued on a second
-        # stream - inside a captured step a parallel branch of the graph - and joined before the exchange / update (~170 of the step's ~700
-        # launches leave the critical path).  MEASURED (round 5, gpurun_out/r5c3): 5.59 -> 10.37 ms per replayed step - a hipGraph with ~120
-        # cross-stream edges replays at roughly two launch boundaries per edge on this runtime - so it is OFF; YK_TRAIN_WSTREAM=1 turns it on.
+        # weight gradients (and the regulariser's dot products) depend on nothing the backward chain waits for: they can run on a second
+        # stream - inside a captured step a parallel branch of the graph - joined before the exchange / update (~170 of the step's ~700 launches
+        # off the critical path).  A cross-stream edge inside a replayed hipGraph is expensive on this runtime: one fork per layer (~120 edges)
+        # measured 5.59 -> 10.37 ms per step (gpurun_out/r5c3), so the deferred launches are flushed to the side stream in
+        # YK_TRAIN_WSTREAM = N chunks (N forks + one join; 0 = everything on one stream, round 4's form).
         import os as _os
-        self.wgrad_stream = _os.environ.get('YK_TRAIN_WSTREAM', '0') != '0'
+        self.wgrad_chunks = max(0, int(_os.environ.get('YK_TRAIN_WSTREAM', '0') or 0))
+        self.wgrad_stream = self.wgrad_chunks > 0
         self._ws = None
         self._graph = None
         self._gx = self._gy = self._gres = self._side = None
@@ -258,15 +260,28 @@ class Trainer:
         if ws is not None:
             ws.wait_stream(main)                                    # G is zero, the forward tape is complete
 
-        def on_side(fn, *tensors):
-            """Run fn() - launches that only WRITE weight gradients - behind everything issued on the main stream so far."""
-            if ws is None:
-                return fn()
+        pending = []                                                # deferred weight-gradient launches of the current chunk
+        n_conv = sum(1 for o in self.spec.ops if o['type'] in (ns.OP_CONV, ns.OP_DWCONV))
+        per_chunk = max(1, -(-n_conv // max(1, self.wgrad_chunks)))
+        seen = [0]
+
+        def flush():
+            """Issue the chunk's deferred launches on the side stream, behind everything the main stream has been given so far."""
+            if ws is None or not pending:
+                return
             ev = torch.cuda.Event()
             ev.record(main)
             ws.wait_event(ev)
             with torch.cuda.stream(ws):
-                fn()
+                for fn in pending:
+                    fn()
+            pending.clear()
+
+        def on_side(fn, *tensors):
+            """fn() only WRITES weight gradients: run it now (no side stream) or defer it to the chunk's flush."""
+            if ws is None:
+                return fn()
+            pending.append(fn)
             keep.extend(tensors)
 
         def acc(tid, g, own):
@@ -290,6 +305,9 @@ class Trainer:
             hi, wi, ci = self.spec.tensors[op['in0']]
             M = self.B * ho * wo
             if t in (ns.OP_CONV, ns.OP_DWCONV):
+                seen[0] += 1
+                if seen[0] % per_chunk == 0:
+                    flush()
                 l = self.lay[op['layer']]
                 w = self.view(self.P, l.name + '/kernel')
                 gw = self.view(self.G, l.name + '/kernel')
@@ -306,13 +324,13 @@ class Trainer:
                     dz = dy
                     if l.use_bias:
                         gb = self.view(self.G, l.name + '/bias')
-                        on_side(lambda dz=dz, gb=gb: self._ck(self.L.yk_colsum_f32(engine._ptr(dz), C.c_longlong(M), C.c_int(co), engine._ptr(gb),
-                                                                                    self._s()), 'yk_colsum_f32'), dz)
+                        on_side(lambda dz=dz, gb=gb, M=M, co=co: self._ck(self.L.yk_colsum_f32(engine._ptr(dz), C.c_longlong(M), C.c_int(co), engine._ptr(gb),
+                                                                                                self._s()), 'yk_colsum_f32'), dz)
                 need_dx = op['in0'] != 0
                 if t == ns.OP_CONV:
                     k = op['k']
                     if k == 1 and op['stride'] == 1:
-                        on_side(lambda dz=dz, x=x, gw=gw: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
+                        on_side(lambda dz=dz, x=x, gw=gw, co=co, ci=ci, M=M: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
                         if need_dx:
                             dx = self._new(self.B, hi, wi, ci)
                             self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)           # dX = dZ * W
@@ -356,6 +374,7 @@ class Trainer:
             elif t == ns.OP_ADD:
                 acc(op['in0'], dy, False)
                 acc(op['in1'], dy, True)
+        flush()
         if ws is not None:
             main.wait_stream(ws)                                    # every weight gradient is in G
         del keep

@@ -15,7 +15,11 @@ from k210_yolo_framework_amd.helper import VOC_ANCHORS
 CASES = [('yolo_mobilev1', 0.75, 224, 320, 32, 'configs[1] (the bench line)'),
          ('tiny_yolo', 1.0, 416, 416, 8, 'configs[2]: 64 images over 8 GPUs'),
          ('yolo_mobilev2', 1.0, 224, 320, 16, 'configs[3] network, inference'),
-         ('yolo', 1.0, 416, 416, 8, 'configs[4]: Darknet-53')]
+         ('yolo', 1.0, 416, 416, 8, 'configs[4]: Darknet-53'),
+         ('yolo', 1.0, 416, 416, 32, 'configs[4]: Darknet-53, 32 images (where the 3x3 layers are MFMA-bound)'),
+         ('yolo', 1.0, 416, 416, 64, 'configs[4]: Darknet-53, 64 images')]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
 print('| network | input | batch | mode | images/s, 1 in flight | images/s, 4 in flight | ms per batch (1 in flight) | note |')
 print('|---|---|---|---|---|---|---|---|')
 for name, alpha, H, W, B, note in CASES:

@@ -7,16 +7,20 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'gpurun_out', 'pmc3')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03_x2'
-meta = json.load(open(os.path.join(root, 'gpurun_out', 'launch_names.json')))
+src = os.path.join(root, 'gpurun_out', sys.argv[2] if len(sys.argv) > 2 else 'pmc3')              # round 5: one directory per launch schedule
+meta = json.load(open(os.path.join(root, 'gpurun_out', sys.argv[3] if len(sys.argv) > 3 else 'launch_names.json')))
 L, kpl = meta['launches'], meta['kernels_per_launch']
 val = collections.defaultdict(dict)            # launch -> counter -> value
 waves_grid = {}
 for sub in 'abc':
     path = os.path.join(src, sub, 'p_counter_collection.csv')
     if not os.path.exists(path):
-        continue
+        import glob
+        hits = glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True)
+        if not hits:
+            continue
+        path = hits[0]
     by_disp = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         d = by_disp.setdefault(int(r['Dispatch_Id']), {'name': r['Kernel_Name'], 'c': {}, 'grid': int(r['Grid_Size']), 'wg': int(r['Workgroup_Size'])})
@@ -50,7 +54,8 @@ for li, nm in enumerate(L):
                 'mfma_busy': round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / (kc * 1024), 4) if kc and 'SQ_VALU_MFMA_BUSY_CYCLES' in v else None,
                 'occupancy_waves_per_simd': round(wc / (kc * 1024), 2) if kc and wc else None,
                 'valu_issue_util': round(v['SQ_INSTS_VALU'] * 4 / (kc * 1024), 3) if kc and 'SQ_INSTS_VALU' in v else None})
-doc = {'_what': 'rocprofv3 --pmc, three separate passes (no trace domains: tools/step_pmc.sh) over tools/one_step.py 3 f16x2 (= one bench.py step, B=32, one '
+doc = {'_schedule': meta.get('schedule'),
+       '_what': 'rocprofv3 --pmc, three separate passes (no trace domains: tools/step_pmc.sh / refresh_profiles5.sh) over tools/one_step.py 3 f16x2 <schedule> (= one bench.py step, B=32, one '
                 'batch in flight); last step, per launch.  kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; busy_* / wait_* are fractions of SQ_WAVE_CYCLES '
                 '(wave-cycles with an instruction of that class in flight / waiting); occupancy = SQ_WAVE_CYCLES / (kernel_cycles * 1024 SIMDs); '
                 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024); lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; '
