@@ -13,8 +13,10 @@ import torch.nn.functional as F
 from k210_yolo_framework_amd import netspec as ns
 
 
-def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None, dtype=torch.float64):
-    """-> dict tensor_id -> NHWC fp32 numpy for ids in `want` (default: spec.outputs)."""
+def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None, dtype=torch.float64, store_hook=None):
+    """-> dict tensor_id -> NHWC fp32 numpy for ids in `want` (default: spec.outputs).
+    store_hook(tensor_id, y_nchw) -> y_nchw: applied to every op's result before it is stored - a storage-format model (e.g. rounding to
+    p significant bits) for pricing inter-layer formats (tools/r05_format_pricing.py); None = exact."""
     want = list(spec.outputs if want is None else want)
     lay = {l.name: l for l in spec.layers}
     T = {0: torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).to(dtype)}
@@ -64,6 +66,8 @@ def forward(spec: ns.NetSpec, weights, x_nhwc: np.ndarray, want=None, dtype=torc
                 y = x + T[op['in1']]
             else:
                 raise ValueError(t)
+            if store_hook is not None:
+                y = store_hook(op['out'], y)
             T[op['out']] = y
     return {i: T[i].permute(0, 2, 3, 1).float().numpy() for i in want}
 
