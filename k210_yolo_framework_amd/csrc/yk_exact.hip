@@ -1431,7 +1431,7 @@ static int x_build_persist(yk_xplan *p, int max_batch) {
     a.CW = CW;
     a.arena = (const uint8_t *)ar;
     a.arena_bytes = (uint32_t)total;
-    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - 2 * (size_t)max_batch * CW * 2));
+    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - 2 * (size_t)max_batch * 2 * CW * 2));
     if ((rc = x_alloc(p, &px, sizeof(uint32_t) * (size_t)max_batch * CW))) return rc;
     a.pxcc = (uint32_t *)px;
     a.err = p->d_err;
@@ -1573,7 +1573,7 @@ static int x_build_heads_from(yk_xplan *p, int max_batch, int first, bool *built
     a.part = (uint8_t *)dpart;
     a.part_stride = poff;
     a.part_bytes = (uint32_t)total;
-    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - (size_t)max_batch * XH_CW * 2));
+    a.gran = reinterpret_cast<unsigned long long *>(p->d_amax + (p->zero_words - (size_t)max_batch * 2 * XH_CW * 2));
     a.pxcc = (uint32_t *)px;
     a.err = p->d_err;
     a.lds_misc = (lds_main + 63u) & ~63u;
@@ -1726,7 +1726,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    p->zero_words = (size_t)n_tensors * max_batch * XS + 2 * (size_t)max_batch * 8 * 2;   // + the barrier granules of the persistent stage and of the heads
+    p->zero_words = (size_t)n_tensors * max_batch * XS + 2 * (size_t)max_batch * 2 * 8 * 2;   // + the barrier granules of the persistent stage and of the heads: [image][barrier parity][member] x 8 bytes each
     if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
     {   // the error word lives in mapped host memory: a failing cluster writes it over the link once, the host polls it for free
         void *h = nullptr, *d = nullptr;

@@ -331,7 +331,7 @@ __device__ __forceinline__ void xh_conv(const xh_args &a, const xh_phase &P, int
     if (P.tw && wid < nown * P.t_ncb) load_tw(wid % P.t_ncb);
     XP_ISTAMP(a, 8 * pi + 3)
     ++arrivals;
-    xp_cluster_barrier(a.gran + (size_t)b * a.CW, a.CW, j, arrivals, 0.f, s_max, a.err);
+    xp_cluster_barrier(a.gran + (size_t)b * 2 * a.CW, a.CW, j, arrivals, 0.f, s_max, a.err);
     XP_ISTAMP(a, 8 * pi + 4)
     // ---- reduce: every partial sum of a tile in flight at once, added in slot order (deterministic); the next tile's are requested
     // before this one's are added
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(XH_NT) xh_kernel(const xh_args a) {
             const xh_phase P = a.ph[pi];                              // by value: the fields live in registers, not behind a pointer
             if (P.pre_barrier) {
                 ++arrivals;
-                xp_cluster_barrier(a.gran + (size_t)b * a.CW, a.CW, j, arrivals, 0.f, s_max, a.err);
+                xp_cluster_barrier(a.gran + (size_t)b * 2 * a.CW, a.CW, j, arrivals, 0.f, s_max, a.err);
             }
             if (P.variant == 0) xh_conv<9, 2, 18, 9, true>(a, P, b, c0, j, same_xcd, s_max, arrivals, pi);
             else if (P.variant == 1) xh_conv<5, 3, 14, 9, false>(a, P, b, c0, j, same_xcd, s_max, arrivals, pi);

@@ -74,7 +74,7 @@ struct xp_args {
     int n_phase, B, CW, n_cluster;
     const uint8_t *arena;              // pointwise weights + the two D buffers: one buffer descriptor
     uint32_t arena_bytes, d_off[2], d_img_stride;
-    unsigned long long *gran;          // [max_batch][CW] {barrier ordinal : 32 | float bits of the member's maximum : 32}, cleared by the step's first launch
+    unsigned long long *gran;          // [max_batch][2 barrier parities][CW] {barrier ordinal : 32 | float bits of the member's maximum : 32}, cleared by the step's first launch
     uint32_t *pxcc;                    // [max_batch][CW] XCD id of every member + 1
     uint32_t *err;                     // sticky: a cluster barrier timed out
     long long *stamps;                 // developer builds: [workgroup][4 * XP_MAXPH + 4] wall_clock64 ticks (100 MHz), or null
@@ -97,20 +97,24 @@ __device__ __forceinline__ void xp_store16_plain(const __amdgpu_buffer_rsrc_t rs
 
 // Every workgroup of the image has finished the phase and its stores are visible.  The data is the flag (guideline 16, R2): a member
 // publishes ONE 8-byte granule {ordinal of this barrier, the maximum of what it wrote}; lanes 0..CW-1 of wave 0 re-read the image's CW
-// granules (one 64-byte line) until every tag carries the ordinal - no counter, no returning atomic, and the maxima arrive with the
-// last tag.  Returns the image's maximum.
+// granules (one 64-byte line) until every tag has REACHED the ordinal - no counter, no returning atomic, and the maxima arrive with the
+// last tag.  Two granule sets alternate by the ordinal's parity (`gran` points at the image's [2][CW] block): a fast member that is
+// already publishing barrier n + 1 writes the other set, so a member that was descheduled before it saw every tag of barrier n still
+// finds them - and their maxima - intact (set n & 1 is next written at barrier n + 2, which nobody reaches before everyone has passed
+// n + 1, hence n).  Tags are compared with >= for the same reason.  Returns the image's maximum.
 __device__ __forceinline__ float xp_cluster_barrier(unsigned long long *gran, int CW, int j, uint32_t ordinal, float wg_max, uint32_t *s_max, uint32_t *err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // every storing wave drains its stores
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
+        unsigned long long *set = gran + (size_t)(ordinal & 1u) * CW;
         if (lane == 0)
-            __hip_atomic_store(gran + j, ((unsigned long long)ordinal << 32) | __float_as_uint(wg_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(set + j, ((unsigned long long)ordinal << 32) | __float_as_uint(wg_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         unsigned long long x = 0;
         for (;;) {
-            x = lane < CW ? __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)ordinal << 32);
-            if (__all((uint32_t)(x >> 32) == ordinal)) break;
+            x = lane < CW ? __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)ordinal << 32);
+            if (__all((uint32_t)(x >> 32) >= ordinal)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) {                               // ~1 s: the members are not co-resident
                 if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mapped host memory: the host polls it
@@ -815,7 +819,7 @@ __global__ void __launch_bounds__(XP_NT) xp_kernel(const xp_args a) {
                 ed = xp_dw(a, P, b, j, ay, same_xcd, s_max, &wg_max);
                 ++arrivals;
                 XP_STAMP(4 * pi + 1)
-                md = xp_cluster_barrier(a.gran + (size_t)b * a.CW, a.CW, j, arrivals, wg_max, s_max, a.err);
+                md = xp_cluster_barrier(a.gran + (size_t)b * 2 * a.CW, a.CW, j, arrivals, wg_max, s_max, a.err);
                 if (arrivals == 1u) {                                 // first barrier of the image: where does everybody run?
                     bool same = true;
                     for (int k = 0; k < a.CW; ++k) same = same && __hip_atomic_load(a.pxcc + (size_t)b * a.CW + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc + 1u;

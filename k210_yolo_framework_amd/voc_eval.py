@@ -5,8 +5,9 @@ The reference publishes no mAP and ships no evaluator (README.md shows demo pict
 widely copied `voc_eval.py` of py-faster-rcnn) defines it:
 
   * per class, detections of ALL images are visited in descending score order;
-  * a detection is a true positive when its best IoU with the not yet matched ground-truth boxes of ITS image and class is
-    >= `iou_thresh` (0.5); that box is then taken.  Otherwise it is a false positive (a second hit on a taken box included);
+  * a detection is compared with ALL ground-truth boxes of ITS image and class (taken or not): the one with the highest IoU decides.
+    IoU >= `iou_thresh` (0.5) on a box nobody has taken yet: true positive, the box is then taken; on an already taken box: FALSE
+    positive (the devkit does not fall back to the second-best box); below the threshold: false positive;
   * boxes flagged `difficult` are neither positives nor negatives: they do not count in the recall denominator and a detection
     matched to one is ignored;
   * AP = area under the monotone precision envelope (VOC2010+, `use_07_metric=False`) or the 11-point mean of it (VOC2007);

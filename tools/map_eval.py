@@ -31,6 +31,8 @@ def ground_truth_rows(boxes: np.ndarray, img_hw) -> np.ndarray:
 
 
 def run(model, h: Helper, rows, obj_thresh, iou_nms, batch=32):
+    # NOTE: detect() keeps at most 30 detections per class and image (keras_inference.py:125 max_output_size=30): at a low obj_thresh the
+    # low-score tail of a crowded image is cut, which lowers recall - and mAP - slightly against an uncapped evaluator.  Printed with the result.
     dets, gts = [], []
     for k in range(0, len(rows), batch):
         imgs = [h._read_img(str(r[0])) for r in rows[k:k + batch]]
@@ -72,7 +74,8 @@ def main(argv=None):
         dets, gts = run(model, h, rows, a.obj_thresh, a.nms_iou)
         r = voc_eval.evaluate(dets, gts, a.class_num, a.iou_thresh, a.voc07)
         res[prec] = r
-        print(f'{prec}: mAP {100 * r["map"]:.2f} over {len(rows)} images ({"VOC07 11-point" if a.voc07 else "area"} AP, IoU {a.iou_thresh})')
+        print(f'{prec}: mAP {100 * r["map"]:.2f} over {len(rows)} images ({"VOC07 11-point" if a.voc07 else "area"} AP, IoU {a.iou_thresh}; '
+              f'obj_thresh {a.obj_thresh}, at most 30 detections per class and image as keras_inference.py:125)')
         for c in range(a.class_num):
             if r['n_gt'][c]:
                 print(f'   class {c:2d}: AP {100 * r["ap"][c]:6.2f}   gt {r["n_gt"][c]:5d}  det {r["n_det"][c]:6d}  tp {r["tp"][c]:5d}')
