@@ -74,7 +74,7 @@ struct igemm_args {
 };
 void yk_fdma_fill(igemm_args &a);   // computes the fp_* fields (a.M = max_batch * Ho * Wo)
 enum { IGEMM_128x64 = 0, IGEMM_128x48, IGEMM_128x96, IGEMM_128x192, IGEMM_64x64, IGEMM_128x128, IGEMM_F32_64x80,
-       IGEMM_F32_128x64, IGEMM_128x64K64, IGEMM_64x128, IGEMM_64x192, IGEMM_256x128 /* developer build only */, IGEMM_256x128W4, IGEMM_128x256, IGEMM_128x128R, IGEMM_256x256, IGEMM_NUM };
+       IGEMM_F32_128x64, IGEMM_128x64K64, IGEMM_64x128, IGEMM_64x192, IGEMM_256x128 /* developer build only */, IGEMM_256x128W4, IGEMM_128x256, IGEMM_128x128R, IGEMM_256x256, IGEMM_LC_256x128, IGEMM_LC_128x128, IGEMM_LC_128x256, IGEMM_NUM };
 int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st);
 int yk_fused_pad();
 int yk_igemm_pick(const igemm_args &a, bool out_f32);

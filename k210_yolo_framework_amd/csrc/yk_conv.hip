@@ -726,6 +726,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_lin_kernel(const igemm_arg
 }
 
 #include "yk_igemm_pipe.h"
+#include "yk_igemm_lc.h"
 
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
     const size_t total = (size_t)a.M * (a.ldn >> 2);
@@ -810,7 +811,8 @@ static const igemm_cfg_info g_cfg[IGEMM_NUM] = {
     {128, 192, 64, "igemm_128x192k64"}, {64, 64, 64, "igemm_64x64k64"}, {128, 128, 64, "igemm_128x128k64"},
     {64, 80, 64, "igemm_f32_64x80k64"}, {128, 64, 32, "igemm_f32_128x64"}, {128, 64, 64, "igemm_128x64k64"},
     {64, 128, 64, "igemm_64x128k64"}, {64, 192, 64, "igemm_64x192k64"}, {256, 128, 64, "igemm_256x128k64"},
-    {256, 128, 64, "igemm_256x128k64w4"}, {128, 256, 64, "igemm_128x256k64"}, {128, 128, 64, "igemm_128x128k64r"}, {256, 256, 64, "igemm_256x256k64"}};
+    {256, 128, 64, "igemm_256x128k64w4"}, {128, 256, 64, "igemm_128x256k64"}, {128, 128, 64, "igemm_128x128k64r"}, {256, 256, 64, "igemm_256x256k64"},
+    {256, 128, 64, "igemm_lc_256x128"}, {128, 128, 64, "igemm_lc_128x128"}, {128, 256, 64, "igemm_lc_128x256"}};
 
 static int yk_big_ring_depth(int cfg) { return cfg == IGEMM_256x128 ? 3 : 2; }
 
@@ -832,13 +834,22 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
     case IGEMM_256x128W4:
     case IGEMM_128x256:
     case IGEMM_128x128R:
-    case IGEMM_256x256: {
+    case IGEMM_256x256:
+    case IGEMM_LC_256x128:
+    case IGEMM_LC_128x128:
+    case IGEMM_LC_128x256: {
         const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
         if ((a.c0p + a.c1p) % 64 || a.c0p % 64 || (uint64_t)a.in0_bytes + margin >= YK_OOB || (uint64_t)a.in1_bytes + margin >= YK_OOB) break;
         const int ns_env = yk_dev_env("YK_NS") ? atoi(yk_dev_env("YK_NS")) : 0;     // (developer build: read per launch, tools/r05_igemm_sweep.py)
         const int ns = ns_env ? ns_env : yk_big_ring_depth(cfg);
         if (cfg == IGEMM_256x128) return ns >= 3 ? launch_pipe<256, 128, 4, 2, 3>(a, st) : launch_pipe<256, 128, 4, 2, 2>(a, st);
         if (cfg == IGEMM_256x128W4) return ns >= 3 ? launch_pipe<256, 128, 2, 2, 3>(a, st) : launch_pipe<256, 128, 2, 2, 2>(a, st);
+        if (cfg >= IGEMM_LC_256x128) {                             // loader / consumer form (yk_igemm_lc.h): no upsampled source
+            if (a.up0) break;
+            if (cfg == IGEMM_LC_256x128) return launch_lc<256, 128, 2, 2, 4, 3>(a, st);
+            if (cfg == IGEMM_LC_128x256) return launch_lc<128, 256, 2, 2, 4, 3>(a, st);
+            return ns >= 4 ? launch_lc<128, 128, 2, 2, 4, 4>(a, st) : launch_lc<128, 128, 2, 2, 4, 3>(a, st);
+        }
         if (cfg == IGEMM_256x256) return launch_pipe<256, 256, 4, 2, 2>(a, st);
         if (cfg == IGEMM_128x256) return ns >= 3 ? launch_pipe<128, 256, 2, 2, 3>(a, st) : launch_pipe<128, 256, 2, 2, 2>(a, st);
         return ns >= 4 ? launch_pipe<128, 128, 2, 2, 4>(a, st) : (ns == 3 ? launch_pipe<128, 128, 2, 2, 3>(a, st) : launch_pipe<128, 128, 2, 2, 2>(a, st));
@@ -885,6 +896,11 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
     {
         const uint64_t margin = (uint64_t)(a.Wi + 2) * (uint64_t)std::max(a.c0p, a.c1p) * 2u + (uint64_t)a.c0p * 2u;
         const bool ring_fits = (uint64_t)a.in0_bytes + margin < YK_OOB && (uint64_t)a.in1_bytes + margin < YK_OOB;   // (the ring kernel has no fallback form)
+        // loader + consumer waves (yk_igemm_lc.h), 128x256 tile.  Alone, on a layer without residual and without split-K, it is ahead on the
+        // long-K wide-N 3x3 layers (tools/r05_igemm_sweep.py, TFLOP/s at 32 / 64 images: 26x26 256->512 686 / 878 vs 658 / 745, 13x13 512->1024
+        // 780 / 800 vs 665 / 708); picked for the whole of Darknet-53 it LOSES (6644 vs 7552 images/s at 32 images, 8328 vs 8708 at 64: its
+        // 128x256 tiles need split-K slabs + a finishing pass where the 64x128 tile fills the chip without) - off unless YK_IGEMM_LC=1
+        if (yk_env_flag("YK_IGEMM_LC", false) && dma_ok && ring_fits && !a.up0 && !a.in1 && a.N % 256 == 0 && a.K >= 1024 && a.M >= 4096) return IGEMM_LC_128x256;
         if (dma_ok && ring_fits && !a.up0 && a.N % 128 == 0 && a.M >= 150000 && a.K >= 256) return IGEMM_128x128R;
     }
     if (a.K >= 512) return (a.N % 128 == 0 && dma_ok) ? IGEMM_64x128 : IGEMM_64x64;

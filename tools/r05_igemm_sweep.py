@@ -2,7 +2,8 @@
 YK_NS and YK_SPLIT_FORCE are read at plan creation / per launch).
     YK_LIB_PATH=.../libyolo_hip_dev.so python tools/r05_igemm_sweep.py [B]
 cfg ids (yk_conv.h): A = the shipped pick, 9 = 64x128k64, 10 = 64x192, 11 = 256x128 on 8 waves, 12 = 256x128 on 4 waves, 13 = 128x256 on 4 waves,
-14 = 128x128 ring kernel, 15 = 256x256 on 8 waves; /n = ring depth."""
+14 = 128x128 ring kernel, 15 = 256x256 on 8 waves, 16 / 17 / 18 = loader + consumer waves (yk_igemm_lc.h) 256x128 / 128x128 / 128x256; /n = ring depth.
+Every variant's network output is compared with the first variant's (max |difference|: the K order is the same, so 0 is expected)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +26,7 @@ for (h, w, c1, c2, k) in shapes:
     wts = s.init_weights(1)
     f = torch.rand(B, h, w, 3, device='cuda')
     line = f'{h}x{w} {c1}->{c2} k{k} B={B} (TF/s): '
+    ref_out = None
     for cfg, nsd in variants:
         for key, val in (('YK_IGEMM_FORCE', cfg), ('YK_NS', nsd), ('YK_SPLIT_FORCE', '1' if cfg else '')):
             if val:
@@ -35,10 +37,14 @@ for (h, w, c1, c2, k) in shapes:
             plan = engine.Plan(s, wts, max_batch=B, precision='f16')
             plan.run_f32(f)
             torch.cuda.synchronize()
+            out = plan.outputs()[0][:B].clone()
+            if ref_out is None:
+                ref_out = out
+            dmax = float((out - ref_out).abs().max())
             ms = plan.profile(f, iters=5)
             hit = [(n, fl, t) for (n, fl, by), t in zip(plan.launches(), ms) if f'_{c1}to{c2}[' in n]
             n, fl, t = hit[0]
-            line += f" {cfg or 'A'}/{nsd or '-'}={fl * B / t / 1e9:.0f}" + (f"[{n.split('[')[1].split(']')[0]}]" if not cfg else '')
+            line += f" {cfg or 'A'}/{nsd or '-'}={fl * B / t / 1e9:.0f}" + (f"[{n.split('[')[1].split(']')[0]}]" if not cfg else '') + (f'(!d={dmax:.3g})' if dmax != 0.0 else '')
             plan.close()
         except Exception as e:
             line += f" {cfg or 'A'}/{nsd or '-'}=ERR({str(e)[:60]})"
