@@ -6,6 +6,7 @@
 #   make bench       images/sec, yolo_mobilev1-0.75, 32 frames per step (GPUS=N runs one rank per GPU through torchrun)
 #   make inference   MODEL=... DEPTHMUL=... CKPT=weights.h5|.npz IMG=picture.jpg
 #   make train       MODEL=... DEPTHMUL=... BATCH=16 MAXEP=10 [SYNTHETIC=256]
+#   make anchors     DATASET=voc ANCNUM=3 [LOW='0.0 0.0' HIGH='1.0 1.0']   (reference Makefile:78-87: k-means anchors from data/<set>_img_ann.npy)
 
 PY            ?= python3
 MODEL         ?= yolo_mobilev1
@@ -31,6 +32,10 @@ IAA           ?= False
 PRUNE         ?= False
 SYNTHETIC     ?= 0
 GPUS          ?= 1
+# anchors only (reference Makefile:27-29)
+ANCNUM        ?= 3
+LOW           ?= 0.0 0.0
+HIGH          ?= 1.0 1.0
 
 NET_ARGS   = --train_set $(DATASET) --class_num $(CLSNUM) --model_def $(MODEL) --depth_multiplier $(DEPTHMUL) \
              --image_size $(IMGSIZE) --output_size $(OUTSIZE) --obj_thresh $(OBJTHRESH) --iou_thresh $(IOUTHRESH)
@@ -44,7 +49,7 @@ else
 LAUNCH = $(PY) -m torch.distributed.run --nnodes=1 --nproc-per-node $(GPUS) --master-addr 127.0.0.1 --master-port 29533
 endif
 
-.PHONY: all build test bench inference train
+.PHONY: all build test bench inference train anchors
 all:
 	@echo 'targets: build | test | bench | inference | train   (see the header of this Makefile)'
 
@@ -62,3 +67,8 @@ inference:
 
 train:
 	$(LAUNCH) keras_train.py $(NET_ARGS) $(TRAIN_ARGS)
+
+# reference Makefile:78-87 (same flags; --is_random True as there)
+anchors:
+	$(PY) ./make_anchor_list.py $(DATASET) --max_iters 10 --is_random True --in_hw $(IMGSIZE) --out_hw $(OUTSIZE) --anchor_num $(ANCNUM) \
+		--low $(LOW) --high $(HIGH)

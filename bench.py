@@ -7,8 +7,8 @@ One "step" = one pass of the hot path over one batch of synthetic u8 frames ALRE
 `value` is quoted in the precision mode whose -m gpu test asserts BASELINE.json's tolerance (scores / coords within 1e-3 of the fp32
 path, identical detection sets): `--precision f16x2`, the default.  The plain fp16-storage mode (5e-3 worst case, tests/test_gpu_e2e.py)
 is measured in the same run and reported under `secondary`.
-`--streams` (default 4) independent batches are kept in flight (step i on stream i mod 4, own plan and decode scratch; measured
-with 8 hardware queues: 3 -> 75.4 k, 4 -> 77.4 k, 5 -> 65 k, 6 -> 70 k images/s);
+`--streams` (default 4) independent batches are kept in flight (step i on stream i mod 4, own plan and decode scratch; the part has four
+compute pipes: 3 -> 79 k, 4 -> 82 k, 5 -> 68 k, 6 -> 72 k, 8 -> 75 k images/s whoever creates the streams, profiles/r05_diag_batch_streams.txt);
 the one-batch-in-flight rate is measured in the same run and reported beside it.
 N>1: one process per GPU (torch.distributed / RCCL used only for the barrier + max-over-ranks of the
 timing); images are sharded across ranks, weights replicated, NO data-path collective ("weak" scaling).  `python bench.py --gpus N`
@@ -22,9 +22,11 @@ is shorter than 0.25 s (K small) the region is repeated and the MEDIAN region ti
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline        the dominant kernel, HIP-event timing on the launch stream, algorithmic bytes = SURVEY 8(d) in+out fp16
   cpu_baseline    the CPU path timed on this box's host cores on a bounded sample (oracle port + torch-CPU/oneDNN graph)
-  secondary       SURVEY 8(d) variants measured with the same harness: letterboxed camera frames, frames from pinned host memory
-                  (H2D + D2H of detections inside the step; PCIe-inclusive, never `value`), the f16x2 precision mode, and the
-                  training step of configs[3].
+  value_from_host the same step fed from pinned host memory (H2D copy in front of the replayed graph, detections written straight into pinned
+                  host memory): SURVEY 8(d)'s "end to end".  It is a top-level field, NOT `value`: the task contract fixes `value` as the rate
+                  with the inputs already resident in HBM and says the PCIe-inclusive rate is never `value`.
+  secondary       SURVEY 8(d) variants measured with the same harness: letterboxed camera frames, eager launches, the f16 precision mode, and
+                  the training step of configs[3].
 """
 import argparse
 import json
@@ -490,7 +492,7 @@ def main():
                     'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None}
         # HBM bytes of that launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
         # tools/one_step.py + tools/profiles_post.py; counters cannot be collected from inside this process)
-        tags = ('r04_x2', 'r03_x2', 'r02') if args.precision == 'f16x2' else ('r03', 'r02', 'r01')
+        tags = ('r05_x2', 'r04_x2', 'r03_x2', 'r02') if args.precision == 'f16x2' else ('r03', 'r02', 'r01')
         for tag in tags:
             try:
                 prof = json.load(open(ROOT / 'profiles' / f'{tag}_hbm_traffic.json'))
@@ -545,6 +547,7 @@ def main():
                                    '(independent batches on separate HIP streams, one plan each)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'launches_per_step': len(launches) + 3,
                        'launch_mode': 'graph' if use_graph else 'eager', 'graph_nodes_per_step': graph_nodes,
+                       'streams': 'created by the library back to back (yk_stream_create): one hardware queue each; more than four lose (4 compute pipes)',
                        'schedule': sched_head,
                        'latency_schedule': {'what': 'the plan of one_batch_in_flight_*: engine.Pipeline(depth=1) -> YK_SCHEDULE_LATENCY (late backbone and heads as '
                                                     'two launches of per-image workgroup clusters)',

@@ -21,7 +21,7 @@ def test_constructor_tables():
     assert np.allclose(h.wh_scale[0], VOC_ANCHORS[0] * [1 / 10, 1 / 7])
     assert np.allclose(h.wh_scale[1][2], [0.08497349 / 20, 0.1527057 / 14])
     assert h.output_shapes == [[None, 7, 10, 3, 25], [None, 14, 20, 3, 25]]
-    assert len(h.colormap) == 40 and h.colormap[0] == (255, 82, 0) and h.colormap[19] == (255, 0, 245)
+    assert len(h.colormap) == 80 and h.colormap[0] == (255, 82, 0) and h.colormap[19] == (255, 0, 245) and h.colormap[79] == (11, 200, 200)
 
 
 def test_three_scale_tables_have_ragged_shapes():
