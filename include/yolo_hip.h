@@ -325,6 +325,10 @@ int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, int Hi, int 
 int yk_bn_train_fwd_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
                         float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
                         float *moving_var, float momentum, void *stream);
+/* ... with the residual of a following keras Add() folded into the apply pass: y = res + act(BN(z)) (keras_mobilenet_v2.py:483-484) */
+int yk_bn_train_fwd_res_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
+                            float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
+                            float *moving_var, float momentum, const float *res, void *stream);
 int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M, int C, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_invstd, int act, float alpha, float *dz, float *dgamma,
                         float *dbeta, void *stream);
@@ -337,6 +341,11 @@ int yk_maxpool2_fwd_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, in
 int yk_maxpool2_bwd_f32(const float *dy, const uint8_t *argmax, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, float *dx,
                         void *stream);
 int yk_dot_f32(long long n, const float *x, const float *y, float alpha, float beta, float *out, void *stream); /* *out = alpha*<x,y> + beta*(*out) */
+/* keras.regularizers.l2(weight) of yolonet.py:245-250 over `nseg` segments of one flat parameter buffer in one pass: *out = weight * sum w^2
+ * (want_value) and / or grads[j] += 2 * weight * params[j] (want_grad).  d_prefix [nseg + 1] = running sum of the segment lengths (device,
+ * int64), d_offset [nseg] = start of every segment in the flat buffer, total = d_prefix[nseg]. */
+int yk_l2_segments_f32(const float *params, float *grads, const long long *d_prefix, const long long *d_offset, int nseg, long long total,
+                       float weight, int want_value, int want_grad, float *out, void *stream);
 int yk_axpy_f32(long long n, float a, const float *x, float *y, void *stream);            /* y += a*x */
 /* keras.optimizers.Adam as keras_train.py:74-76 configures it (lr, decay; beta 0.9/0.999, eps 1e-7):
  * lr_t = lr/(1+decay*iterations) * sqrt(1-b2^t)/(1-b1^t), t = iterations+1; p -= lr_t*m/(sqrt(v)+eps).

@@ -231,6 +231,54 @@ extern "C" int yk_dot_f32(long long n, const float *x, const float *y, float alp
     return YK_OK;
 }
 
+// keras.regularizers.l2(weight) over SEGMENTS of one flat parameter buffer (yolonet.py:245-250: every DarknetConv2D kernel): the value
+// weight * sum w^2 and / or the gradient 2 * weight * w added to the flat gradient buffer, for all segments in ONE pass (round 4: a dot
+// product - two launches - and an axpy per layer: 52 launches of ~5 us on the step's critical path).  Fixed-order two-stage sum in double.
+__global__ void __launch_bounds__(256) l2_seg_kernel(const float *__restrict__ P, float *__restrict__ G, const long long *__restrict__ pre,
+                                                     const long long *__restrict__ off, int nseg, float two_w, int want_value, int want_grad,
+                                                     double *__restrict__ part) {
+    __shared__ double red[256];
+    const long long total = pre[nseg];
+    double s = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        const long long j = off[lo] + (i - pre[lo]);
+        const float w = P[j];
+        s += (double)w * (double)w;
+        if (want_grad) G[j] += two_w * w;
+    }
+    if (!want_value) return;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+extern "C" int yk_l2_segments_f32(const float *params, float *grads, const long long *d_prefix, const long long *d_offset, int nseg, long long total,
+                                  float weight, int want_value, int want_grad, float *out, void *stream) {
+    if (!params || !d_prefix || !d_offset || nseg <= 0 || total <= 0 || (want_grad && !grads) || (want_value && !out)) {
+        yk_set_error("yk_l2_segments_f32: bad argument");
+        return YK_ERR_ARG;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    const int blocks = (int)std::min<long long>(512, (total + 255) / 256);
+    double *part = (double *)yk_scratch(dev, stream, 15, sizeof(double) * 512);
+    if (!part) return YK_ERR_NOMEM;
+    hipLaunchKernelGGL(l2_seg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, d_prefix, d_offset, nseg, 2.f * weight, want_value,
+                       want_grad, part);
+    if (want_value) hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)part, blocks, weight, 0.f, out);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+
 // --------------------------------------------------------------------------------------------------------
 // im2col / col2im for 3x3 convs, NHWC.  col: [B*Ho*Wo][9*C] with k = (ky*3+kx)*C + c (matches OHWI weights).
 // --------------------------------------------------------------------------------------------------------
@@ -661,7 +709,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finish_kernel(const float *__restr
 template <int V>
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float *__restrict__ z, size_t total, int C, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, int act, float alpha, float *__restrict__ y) {
+                                                           const float *__restrict__ beta, int act, float alpha, float *__restrict__ y,
+                                                           const float *__restrict__ res) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= total) return;
     const int c = (int)(i % C);
@@ -669,6 +718,12 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float *__restri
     ldv<V>(z + i, zv); ldv<V>(mean + c, mu); ldv<V>(invstd + c, is); ldv<V>(gamma + c, ga); ldv<V>(beta + c, be);
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = t_act(ga[k] * (zv[k] - mu[k]) * is[k] + be[k], act, alpha);
+    if (res) {                                                   // keras Add()([res, this layer's output]) folded into the apply pass
+        float rv[V];
+        ldv<V>(res + i, rv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = rv[k] + o[k];
+    }
     stv<V>(y + i, o);
 }
 template <int V>
@@ -701,9 +756,21 @@ static int bn_chunking(size_t M, int C, int *rows_per_chunk, int *cwl) {
     return (int)((M + rpc - 1) / rpc);
 }
 
+static int bn_train_fwd(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act, float alpha, float *y,
+                        float *save_mean, float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream);
 extern "C" int yk_bn_train_fwd_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
                                    float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
                                    float *moving_var, float momentum, void *stream) {
+    return bn_train_fwd(z, M, C, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, nullptr, stream);
+}
+// the same with the residual of a following keras Add() folded in: y = res + act(BN(z))  (keras_mobilenet_v2.py:483-484, yolonet.py:203)
+extern "C" int yk_bn_train_fwd_res_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
+                                       float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
+                                       float *moving_var, float momentum, const float *res, void *stream) {
+    return bn_train_fwd(z, M, C, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res, stream);
+}
+static int bn_train_fwd(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act, float alpha, float *y,
+                        float *save_mean, float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream) {
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
     int rpc, cwl;
@@ -720,10 +787,10 @@ extern "C" int yk_bn_train_fwd_f32(const float *z, long long M, int C, const flo
     const size_t total = (size_t)M * C;
     if (C % 4 == 0)
         hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
-                           (const float *)save_invstd, gamma, beta, act, alpha, y);
+                           (const float *)save_invstd, gamma, beta, act, alpha, y, res);
     else
         hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
-                           (const float *)save_invstd, gamma, beta, act, alpha, y);
+                           (const float *)save_invstd, gamma, beta, act, alpha, y, res);
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

@@ -89,6 +89,8 @@ class Trainer:
         self.wgrad_chunks = max(0, int(_os.environ.get('YK_TRAIN_WSTREAM', '0') or 0))
         self.wgrad_stream = self.wgrad_chunks > 0
         self._ws = None
+        self._l2_seg = None
+        self._fa = None
         self._graph = None
         self._gx = self._gy = self._gres = self._side = None
         self._eager_steps = 0
@@ -176,13 +178,40 @@ class Trainer:
     def _axpy(self, a, x, y):
         self._ck(self.L.yk_axpy_f32(C.c_longlong(x.numel()), C.c_float(a), engine._ptr(x), engine._ptr(y), self._s()), 'yk_axpy_f32')
 
+    def _fused_adds(self):
+        """conv op index -> (index of the Add that consumes ONLY-there its output, the Add's other input).  The Add is folded into that
+        conv's BatchNorm apply pass when the conv has BatchNorm, its output has no other reader and is not a network output, and the Add
+        follows before anything else needs the output (residual blocks: keras_mobilenet_v2.py:483-484, yolonet.py:194-204)."""
+        if self._fa is None:
+            ops, fa = self.spec.ops, {}
+            readers = {}
+            for k, o in enumerate(ops):
+                for key in ('in0', 'in1'):
+                    if o.get(key, -1) is not None and o.get(key, -1) >= 0:
+                        readers.setdefault(o[key], []).append(k)
+            for k, o in enumerate(ops):
+                if o['type'] != ns.OP_ADD:
+                    continue
+                for mine, other in ((o['in1'], o['in0']), (o['in0'], o['in1'])):
+                    prod = [j for j, q in enumerate(ops) if q['out'] == mine and q['type'] in (ns.OP_CONV, ns.OP_DWCONV)]
+                    if (len(prod) == 1 and self.lay[ops[prod[0]]['layer']].bn_name and readers.get(mine, []) == [k] and mine not in self.spec.outputs
+                            and mine != other and all(q['out'] != other for q in ops[prod[0]:k])):
+                        fa[prod[0]] = (k, other)
+                        break
+            self._fa = fa
+        return self._fa
+
     # ------------------------------------------------------------------ forward (training mode)
     def forward(self, x_nhwc) -> List["torch.Tensor"]:
         """x_nhwc: cuda fp32 [B,H,W,3] already normalised (Helper._process_img output).  Saves the tape."""
         torch = self.torch
         assert x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[:1]) == (self.B,)
         T, S = {0: x_nhwc.contiguous()}, {}
+        fused_add = self._fused_adds()                               # conv op index -> (Add op index, the Add's other input)
+        done = set()
         for i, op in enumerate(self.spec.ops):
+            if i in done:
+                continue
             x, t = T[op['in0']], op['type']
             ho, wo, co = self.spec.tensors[op['out']]
             M = self.B * ho * wo
@@ -205,14 +234,19 @@ class Trainer:
                 if l.bn_name:
                     y = self._new(self.B, ho, wo, co)
                     mean, invstd = self._new(co), self._new(co)
-                    self._ck(self.L.yk_bn_train_fwd_f32(
+                    fa = fused_add.get(i)
+                    res = T[fa[1]] if fa is not None else None       # keras Add()([res, this output]) folded into the apply pass
+                    self._ck(self.L.yk_bn_train_fwd_res_f32(
                         engine._ptr(z), C.c_longlong(M), C.c_int(co), engine._ptr(self.view(self.P, l.bn_name + '/gamma')),
                         engine._ptr(self.view(self.P, l.bn_name + '/beta')), C.c_float(ns.BN_EPS), C.c_int(op['act']),
                         C.c_float(op['alpha']), engine._ptr(y), engine._ptr(mean), engine._ptr(invstd),
                         engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
                         C.c_float(BN_MOMENTUM_V2 if self.spec.name == 'yolo_mobilev2' and not _is_darknet_conv(l.name) else BN_MOMENTUM),
-                        self._s()), 'yk_bn_train_fwd_f32')
+                        engine._ptr(res) if res is not None else None, self._s()), 'yk_bn_train_fwd_res_f32')
                     S[i] = dict(z=z, mean=mean, invstd=invstd)
+                    if fa is not None:                               # y IS the Add's output; the conv's own output tensor is never needed again
+                        T[self.spec.ops[fa[0]]['out']] = y
+                        done.add(fa[0])
                 else:
                     assert op['act'] == ns.ACT_NONE
                     if l.use_bias:
@@ -372,8 +406,19 @@ class Trainer:
                 acc(op['in0'], dy[..., :c0].contiguous(), True)
                 acc(op['in1'], dy[..., c0:].contiguous(), True)
             elif t == ns.OP_ADD:
-                acc(op['in0'], dy, False)
-                acc(op['in1'], dy, True)
+                # dL/d(in0) = dL/d(in1) = dy.  The two entries may SHARE dy's buffer (no clone) when nothing accumulates into either of them
+                # before the other one has been consumed: every other reader of one input precedes the producer of the other input, i.e.
+                # the backward loop pops the producer's entry first (the residual blocks of both networks)
+                a_, b_ = op['in0'], op['in1']
+                pa = max([j for j, q in enumerate(self.spec.ops) if q['out'] == a_], default=-1)
+                pb = max([j for j, q in enumerate(self.spec.ops) if q['out'] == b_], default=-1)
+                first, second = (a_, b_) if pa > pb else (b_, a_)     # `first` is popped first (its producer comes later in the forward order)
+                pf = max(pa, pb)
+                others = [j for j, q in enumerate(self.spec.ops) if j != i and (q.get('in0') == second or q.get('in1') == second)]
+                lone = not [j for j, q in enumerate(self.spec.ops) if j != i and (q.get('in0') == first or q.get('in1') == first)] and first not in self.spec.outputs
+                share = a_ != b_ and lone and first not in D and second not in D and all(j < pf for j in others) and second != 0
+                acc(second, dy, share)
+                acc(first, dy, True)
         flush()
         if ws is not None:
             main.wait_stream(ws)                                    # every weight gradient is in G
@@ -381,17 +426,22 @@ class Trainer:
 
     # ------------------------------------------------------------------ one optimisation step
     def regulariser(self, add_grad: bool, value: bool = True) -> "torch.Tensor":
-        """sum over DarknetConv2D kernels of 5e-4 * sum(w^2) (device scalar; value=False skips it); optionally G += 2*5e-4*W."""
-        tot = self.torch.zeros(1, dtype=self.torch.float32, device=self.dev) if value else None
-        for l in self.spec.layers:
-            if l.kind == 'conv' and _is_darknet_conv(l.name):
-                w = self.view(self.P, l.name + '/kernel')
-                n = w.numel()
-                if value:
-                    self._ck(self.L.yk_dot_f32(C.c_longlong(n), engine._ptr(w), engine._ptr(w), C.c_float(L2_WEIGHT), C.c_float(1.0),
-                                               engine._ptr(tot), self._s()), 'yk_dot_f32')                # tot += 5e-4 * <w, w>
-                if add_grad:
-                    self._axpy(2.0 * L2_WEIGHT, w, self.view(self.G, l.name + '/kernel'))
+        """sum over DarknetConv2D kernels of 5e-4 * sum(w^2) (device scalar; value=False skips it); optionally G += 2*5e-4*W.
+        One pass over all of those kernels (yk_l2_segments_f32: they are segments of the flat parameter buffer) - two launches instead of
+        a dot product and an axpy per layer."""
+        torch = self.torch
+        if self._l2_seg is None:
+            segs = [(self.slots[l.name + '/kernel'][0], int(np.prod(self.slots[l.name + '/kernel'][1])))
+                    for l in self.spec.layers if l.kind == 'conv' and _is_darknet_conv(l.name)]
+            pre = np.concatenate([[0], np.cumsum([n for _, n in segs])]).astype(np.int64)
+            self._l2_seg = (torch.from_numpy(pre).to(self.dev), torch.from_numpy(np.asarray([o for o, _ in segs], np.int64)).to(self.dev), len(segs),
+                            int(pre[-1]))
+        pre, off, nseg, total = self._l2_seg
+        tot = torch.zeros(1, dtype=torch.float32, device=self.dev) if value else None
+        if nseg and (value or add_grad):
+            self._ck(self.L.yk_l2_segments_f32(engine._ptr(self.P), engine._ptr(self.G), engine._ptr(pre), engine._ptr(off), C.c_int(nseg),
+                                               C.c_longlong(total), C.c_float(L2_WEIGHT), C.c_int(1 if value else 0), C.c_int(1 if add_grad else 0),
+                                               engine._ptr(tot) if value else None, self._s()), 'yk_l2_segments_f32')
         return tot
 
     def loss_and_grads(self, x_nhwc, y_true: Sequence["torch.Tensor"]):
