@@ -3,7 +3,8 @@
     python tools/darknet_layers.py [f16|f16x2] [B]
 """
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from k210_yolo_framework_amd import engine, netspec as ns

@@ -3,7 +3,8 @@
     python tools/xbench.py [net] [B]          (environment: YK_FUSE_DWPW, YK_X_FUSE_MAXC, YK_X_BN, YK_X_PATCH, YK_X_SPLITK)
 """
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import oracle
