@@ -1098,27 +1098,29 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
     return YK_ERR_ARG;
 }
 
-template <int TM, int TN, bool STEM>
+template <int TM, int TN, int SG>
 int x_launch_b2(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
     static unsigned allowed = 64 * 1024;
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN, STEM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN, SG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         allowed = 160 * 1024;
     }
     dim3 grid((unsigned)(batch * g.tiles_x * g.tiles_y), (unsigned)((g.N + 64 * TN - 1) / (64 * TN)));
-    hipLaunchKernelGGL((xb_kernel<TM, TN, STEM>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((xb_kernel<TM, TN, SG>), grid, dim3(256), lds, st, g);
     return YK_OK;
 }
 template <int TM, int TN>
 int x_launch_b(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
     if constexpr (TN == 1) {                                       // the stem-fed block of every network here has <= 64 output channels
-        if (g.stem) return x_launch_b2<TM, TN, true>(g, batch, lds, st);
+        if (g.stem && g.GL == 2) return x_launch_b2<TM, TN, 2>(g, batch, lds, st);   // 16 / 24 / 32 stem filters
+        if (g.stem && g.GL == 3) return x_launch_b2<TM, TN, 3>(g, batch, lds, st);
+        if (g.stem && g.GL == 4) return x_launch_b2<TM, TN, 4>(g, batch, lds, st);
     }
     if (g.stem) {
-        yk_set_error("f16x2: stem fusion needs an N tile of 64");
+        yk_set_error("f16x2: stem fusion needs an N tile of 64 and 16, 24 or 32 stem filters");
         return YK_ERR_UNSUPPORTED;
     }
-    return x_launch_b2<TM, TN, false>(g, batch, lds, st);
+    return x_launch_b2<TM, TN, 0>(g, batch, lds, st);
 }
 const int g_xb_tm[] = {2, 3, 4, 5, 8}, g_xb_tn[] = {1, 2, 3, 6};
 bool xb_has(int tm, int tn) {
@@ -1206,6 +1208,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
     g.fd_tw = yk_make_fastdiv((uint32_t)g.TW);
     g.fd_pw = yk_make_fastdiv((uint32_t)g.PW);
     g.fd_nk = yk_make_fastdiv((uint32_t)std::max(1, g.nk));
+    g.GL = 4;
     return true;
 }
 
@@ -1700,9 +1703,20 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             if (d[YK_F_TYPE] != YK_OP_DWCONV || d[YK_F_IN0] != y || dw_of[i + 2] != i + 1 || p->T[y].uses != 1 || o[YK_F_K] != 3 ||
                 (co != 16 && co != 24 && co != 32) || (o[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT))
                 continue;
-            const xfuse &f = fuse[i + 2];
+            xfuse &f = fuse[i + 2];
             const int st = o[YK_F_STRIDE], WR = (f.g.PH - 1) * st + 3, WC = (f.g.PW - 1) * st + 3;
-            if ((size_t)WR * WC * 3 * 4 > (size_t)16 * f.tm * 128 || f.g.nk != 1 || f.tn != 1) continue;
+            if (f.g.nk != 1 || f.tn != 1) continue;
+            // the patch and the A tile of a stem-fed block hold the channel groups the stem HAS (yk_xblock.h: xb_args::GL); the A tile's
+            // space first holds the frame window (fp32 frames: WR x WC x 3 floats), so it is at least that large
+            const int GL = co / 8, n16 = f.g.PH * f.g.PW * GL, n16p = (n16 + 63) & ~63;
+            const int abytes = std::max(16 * f.tm * GL * 32, (WR * WC * 3 * 4 + 8 + 63) & ~63);
+            const int ring = n16p * 32 + 2048 + f.g.bt_bytes + abytes, ct = f.tm * 16 * (64 * 4 + 16);
+            const unsigned lds = (unsigned)(std::max(ring, ct) + 64);
+            if (lds > f.lds) continue;
+            f.g.GL = GL;
+            f.g.n16 = n16; f.g.n16p = n16p;
+            f.g.lds_bytes = (int)lds;
+            f.lds = lds;
             stem_of[i + 2] = i;
             skip[i] = 1;
             gone[y] = 1;

@@ -61,6 +61,9 @@ struct xb_args {
     int st_e;
     yk_fastdiv fd_wrow;                // division by the window row length (WC * 3)
     yk_fastdiv fd_dpr;                 // division by the window row length in dwords (u8 frames: the window stays bytes in LDS)
+    // fused stem: the patch and the A tile hold the GL channel groups that EXIST (24 stem filters: three groups of 8, 48 bytes per position /
+    // A row per plane instead of 64): 39 KB instead of 49 - a FOURTH workgroup per CU - and the depthwise pass has no dead items
+    int GL;
     int dbg;
     long long *stamps;                 // developer builds: per-workgroup phase timestamps [wg][16] (wall_clock64), or null
 };
@@ -89,7 +92,7 @@ struct xb_cfg {
 // `img / np.max(img)` (tools/utils.py:405) moves behind the sum: conv(img) * (scale / max) in fp32 - two MFMAs per tile instead of
 // three, no per-pixel split.  f32 frames: the window is fp32, already normalised by the caller; the operand is split as everywhere.
 // The storage exponent of the stem's output is a plan constant (the image is in [0, 1]), folded into scale, bias and cap.
-template <bool U8>
+template <bool U8, int GL>
 __device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp, int WC, int pitch, float inv, int iy0, int ix0, unsigned char *HI, unsigned char *LO) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     half8 wfh[2], wfl[2];
@@ -163,18 +166,21 @@ __device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp
             }
             // the patch of a fused stem is fp32: [position][4 groups][channels 0-3] in the first plane, [..][channels 4-7] in the second (what
             // the depthwise taps multiply; round 3 stored (hi | lo) here and every tap converted them back, 72 VALU operations per item)
-            if (valid) {
-                const int n = nf * 16 + fq * 4, at = (pos * 4 + (n >> 3)) * 16;
+            const int n = nf * 16 + fq * 4;
+            if (valid && (n >> 3) < GL) {
+                const int at = (pos * GL + (n >> 3)) * 16;
                 *reinterpret_cast<u32x4 *>(((n & 4) ? LO : HI) + at) = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             }
         }
     }
 }
 
-template <int TM, int TN, bool STEM>
-__global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb_args a) {   // 2 (3) workgroups per CU: <= 256 (168) registers
+template <int TM, int TN, int SG>                                     // SG: 0 = the input is a stored tensor; 2, 3, 4 = fused stem with SG channel groups
+__global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb_args a) {   // 2 (3) workgroups per CU: <= 256 (168) registers; the fused-stem block stays under 128 by itself (4 per CU)
     typedef xb_cfg<TM, TN> C;
     constexpr int BM = C::BM, BN = C::BN;
+    constexpr bool STEM = SG > 0;
+    constexpr int GL = STEM ? SG : 4;                                 // channel groups per patch position and per A row
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = a.in.G, s = a.stride;
 #ifdef YK_DEV
@@ -346,8 +352,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         XB_STAMP(12)
         // (2) one thread = one patch position, all st_cout channels
         unsigned char *HI = xsm, *LO = xsm + a.n16p * 16;
-        if (a.in_f32) xb_stem_patch<false>(a, A, WC, 0, 1.f, iy0, ix0, HI, LO);
-        else xb_stem_patch<true>(a, A, WC, ((WC * 3 + 3) >> 2) * 4, inv, iy0, ix0, HI, LO);
+        if (a.in_f32) xb_stem_patch<false, GL>(a, A, WC, 0, 1.f, iy0, ix0, HI, LO);
+        else xb_stem_patch<true, GL>(a, A, WC, ((WC * 3 + 3) >> 2) * 4, inv, iy0, ix0, HI, LO);
     }
     XB_STAMP(1)
     // per-image factors (one image per workgroup)
@@ -378,7 +384,11 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     const bool wave_live = n0 + wid * TN * 16 < a.N;                  // wave-uniform
+    // fragment offsets: rows of 64 bytes with the 16-byte pieces swizzled (weight tile; A tile of a stored-tensor block), rows of GL * 16
+    // bytes in a fused-stem block (48-byte rows of a 24-channel stem touch every bank once per 16 lanes without a swizzle)
     const int foff = fr * 64 + ((fq ^ ((fr >> 1) & 3)) * 16);
+    // (a k group the stem does not have: the lane re-reads group 0 - finite values against weight rows that are zero)
+    const int afoff = fr * (GL * 16) + (GL == 4 ? (fq ^ ((fr >> 1) & 3)) : (fq < GL ? fq : 0)) * 16;
     const int nk = X_DBG(a, 1) ? 0 : a.nk;
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of patch(ks) have landed
@@ -418,19 +428,26 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
         }
         // ---- depthwise: item = (pixel p, group q of this step)
         if (!X_DBG(a, 2))
-            for (int it = tid; it < BM * 4; it += 256) {
-                const int p = it >> 2, q = it & 3;
+            for (int it = tid; it < BM * GL; it += 256) {
+                int p, q;
+                if constexpr (GL != 4) {
+                    p = (int)((uint32_t)it / (uint32_t)GL);
+                    q = it - p * GL;
+                } else {
+                    p = it >> 2;
+                    q = it & 3;
+                }
                 const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
                 const bool live = py < a.TH && oy0 + py < a.Ho && ox0 + px < a.Wo;
                 half8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
                 if (live) {
-                    const int base = ((py * s) * a.PW + px * s) * 4 + q;
+                    const int base = ((py * s) * a.PW + px * s) * GL + q;
                     // x = hi + lo back in fp32 by one mixed-precision op per channel, then packed fp32 FMAs (two channels per
                     // instruction): 12 VALU ops per tap and channel group instead of 16
                     float2v d2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const int at = (base + ((t / 3) * a.PW + (t % 3)) * 4) * 16;
+                        const int at = (base + ((t / 3) * a.PW + (t % 3)) * GL) * 16;
                         const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
                         const u32x4 w0 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8) * 4), w1 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8 + 4) * 4);
                         const float2v w2[4] = {{__uint_as_float(w0[0]), __uint_as_float(w0[1])}, {__uint_as_float(w0[2]), __uint_as_float(w0[3])},
@@ -461,9 +478,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
                     x_split8(vd, hi, lo);
                 }
                 const int r = p & 15;
-                unsigned char *dst = A + (p >> 4) * 2048 + r * 64 + ((q ^ ((r >> 1) & 3)) * 16);
+                unsigned char *dst = A + (p >> 4) * (GL * 512) + r * (GL * 16) + ((q ^ (GL == 4 ? (r >> 1) & 3 : 0)) * 16);
                 *reinterpret_cast<half8 *>(dst) = hi;
-                *reinterpret_cast<half8 *>(dst + 1024) = lo;
+                *reinterpret_cast<half8 *>(dst + GL * 256) = lo;
             }
         if (ks == 0) { XB_STAMP(4) }
         if (a.db) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (step ks+1 stays in flight)
@@ -478,8 +495,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 3)) xb_kernel(const xb
             half8 xh[TM], xl[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                xh[i] = *reinterpret_cast<const half8 *>(A + i * 2048 + foff);
-                xl[i] = *reinterpret_cast<const half8 *>(A + i * 2048 + 1024 + foff);
+                xh[i] = *reinterpret_cast<const half8 *>(A + i * (GL * 512) + afoff);
+                xl[i] = *reinterpret_cast<const half8 *>(A + i * (GL * 512) + GL * 256 + afoff);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
