@@ -646,7 +646,7 @@ struct xdw_args {
     int in_f32;                        // the input is stored as fp32 planes (its only reader is this kernel): the taps read floats
     yk_fastdiv fd_gsl, fd_tpi, fd_tx, fd_gs, fd_pw, fd_tw;
 };
-__global__ void __launch_bounds__(256) xdw_kernel(const xdw_args a) {
+__global__ void __launch_bounds__(256, 4) xdw_kernel(const xdw_args a) {   // <= 128 registers: four workgroups per CU (the patch is <= 40 KB)
     __shared__ uint32_t smax;
     __shared__ float sf[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, G = a.in.G, Cp = G * 8, s = a.stride;
@@ -1142,13 +1142,14 @@ int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hi
     yk_set_error("f16x2: no fused block kernel <%d,%d>", tm, tn);
     return YK_ERR_ARG;
 }
-// the weight tile holds the 16-channel blocks that exist: N = 96 in a 128-wide tile needs 12 KB, not 16 - which is what lets a FOURTH
-// workgroup of the 96 -> 96 block onto a CU (36.8 KB each instead of 40.8)
+// LDS of a fused block: patch (hi | lo planes) + depthwise parameters per stage, the A tile, or the output staging if that is larger.
+// The pointwise weights are NOT staged (each wave loads its own fragments into registers): `wt` adds the tile they used to take, which
+// is what the tile-selection rule below was measured with (rounds 3-4) and still uses, so that the tiles stay the measured ones
 int xb_bt_bytes(int tn, int N) { return std::min(64 * tn, (N + 15) / 16 * 16) * 128; }
-unsigned xb_lds(int tm, int tn, int n16p, int db, int N) {
+unsigned xb_lds(int tm, int tn, int n16p, int db, int N, bool wt = false) {
     const int bm = 16 * tm, bn = 64 * tn;
     const int ipp = (tn >= 3 && tm >= 2) ? (tm + 1) / 2 : tm;
-    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + xb_bt_bytes(tn, N)) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
+    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + (wt ? xb_bt_bytes(tn, N) : 0)) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
     return (unsigned)(std::max(ring, ct) + 64);
 }
 // Tile geometry of a fused block.  Measured on K2 at B=32 (tools/xbsweep.py: every (TM, TN, tile width, stages) per block): the launch
@@ -1182,7 +1183,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                 for (int db = 0; db <= 1; ++db) {
                     if (force_db >= 0 ? db != force_db : db != 0) continue;
                     const unsigned lds = xb_lds(tm, tn, n16p, db, g.N);
-                    if (lds > 160 * 1024 || (!forced && lds > 53 * 1024 + 512)) continue;
+                    if (lds > 160 * 1024 || (!forced && xb_lds(tm, tn, n16p, db, g.N, true) > 53 * 1024 + 512)) continue;
                     const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
                     const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
                     const double halo = (double)TH * TW * s * s / ((double)PH * PW);       // bytes used / bytes staged
@@ -1191,7 +1192,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                         best = score;
                         *tm_out = tm; *tn_out = tn; *lds_out = lds;
                         g.TH = TH; g.TW = TW; g.PH = PH; g.PW = PW; g.n16 = n16; g.n16p = n16p; g.db = db;
-                        g.bt_bytes = xb_bt_bytes(tn, g.N); g.lds_bytes = (int)lds;
+                        g.lds_bytes = (int)lds;
                         // converting a stored patch to fp32 once instead of in every tap: measured slower (49.8 vs 45.3 us, 35.3 vs 32.8 us on the
                         // two stride-1 blocks: the extra barrier and LDS pass cost more than the 60 conversions per item they save); the
                         // fused stem writes its patch as fp32 directly (84 -> 78 us)
@@ -1665,6 +1666,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     std::vector<char> gone(n_tensors, 0);
     int n_fused_seen = 0;
     const bool fuse_blocks = yk_env_flag("YK_FUSE_DWPW", true) && !yk_dev_env("YK_X_NOFUSE");
+    const bool persist_on = yk_env_flag("YK_PERSIST", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOPERSIST");
     if (fuse_blocks)
         for (int i = 0; i + 1 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
@@ -1684,8 +1686,12 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             // is faster (28 vs 39 us, 34 vs 60 us): too few workgroups to hide the fused pipeline's per-step DMA round trips
             // (the rule looks at the image only, not at max_batch: whether a block is fused changes its rounding, and an image's
             // results must not depend on how many images the plan was built for)
-            // and up to 192 input channels: from 384 on the two-launch form ties or wins (39.8 vs 44 us at 14x20x384)
-            if ((f.g.Ho * f.g.Wo < 128 || f.g.nk > 6) && !yk_dev_env("YK_XB_ALWAYS")) continue;
+            // and up to 384 input channels (round 5, with the weight fragments out of LDS: 35.8 us against 16 + 21.5 at 14x20x384, +4.7 % images/s
+            // with four batches in flight; rounds 3-4, with the weight tile in LDS, had the two-launch form ahead from 384 on).  Where the
+            // persistent stage takes the 14x20x384 blocks (latency schedule) they stay separate launches for it to collect.
+            const int max_nk = yk_dev_env("YK_XB_MAXNK") ? atoi(yk_dev_env("YK_XB_MAXNK")) : (persist_on ? 6 : 12);
+            const int min_px = yk_dev_env("YK_XB_MINPX") ? atoi(yk_dev_env("YK_XB_MINPX")) : 128;
+            if ((f.g.Ho * f.g.Wo < min_px || f.g.nk > max_nk) && !yk_dev_env("YK_XB_ALWAYS")) continue;
             if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch, n_fused_seen++)) continue;
             dw_of[i + 1] = i;
             skip[i] = 1;
@@ -1710,7 +1716,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             // space first holds the frame window (fp32 frames: WR x WC x 3 floats), so it is at least that large
             const int GL = co / 8, n16 = f.g.PH * f.g.PW * GL, n16p = (n16 + 63) & ~63;
             const int abytes = std::max(16 * f.tm * GL * 32, (WR * WC * 3 * 4 + 8 + 63) & ~63);
-            const int ring = n16p * 32 + 2048 + f.g.bt_bytes + abytes, ct = f.tm * 16 * (64 * 4 + 16);
+            const int ring = n16p * 32 + 2048 + abytes, ct = f.tm * 16 * (64 * 4 + 16);
             const unsigned lds = (unsigned)(std::max(ring, ct) + 64);
             if (lds > f.lds) continue;
             f.g.GL = GL;
@@ -2199,7 +2205,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     // The two cluster launches hold every CU for their whole duration: the shortest time of ONE batch (one-batch latency 669 -> 542 us of
     // kernels), but with several batches in flight on several streams the launch-per-layer form overlaps better (78 k vs 68 k images/s, four in
     // flight; profiles/r04_schedules.txt).  YK_SCHEDULE_LATENCY selects them; YK_PERSIST / YK_HEADS = 0|1 override either way.
-    if (yk_env_flag("YK_PERSIST", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOPERSIST")) {      // YK_FUSE_DWPW=0: one launch per layer
+    if (persist_on) {                                               // (YK_FUSE_DWPW=0: one launch per layer)
         if ((rc = x_build_persist(p, max_batch))) return fail(rc);
     }
     if (yk_env_flag("YK_HEADS", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOHEADS")) {

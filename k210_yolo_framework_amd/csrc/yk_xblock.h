@@ -46,7 +46,7 @@ struct xb_args {
     // A tensor whose only consumer is the depthwise conv of another fused block is stored as FP32 ([pixel][group][ch 0-3 | ch 4-7], the same
     // 32 bytes per group as (hi | lo), exponent 0): its producer skips the split, its consumer's taps skip 72 conversions per item
     int src_f32, dst_f32;
-    int bt_bytes, lds_bytes;           // pointwise weight tile in LDS: 2 KB per 16-channel block that EXISTS (N = 96 in a 128-wide tile: 12 KB, not 16), total dynamic LDS
+    int lds_bytes;                     // total dynamic LDS
     yk_fastdiv fd_tpi, fd_tx, fd_tw, fd_pw, fd_nk;
     // fused stem: the block's depthwise input is the output of the network's FIRST conv (3 input channels, <= 32 filters), computed in
     // this kernel from the frames; that tensor (55 MB per batch of 32 at 224x320) is then never written nor read
@@ -74,7 +74,7 @@ struct xb_cfg {
     static constexpr int PARB = 2048;                             // 11 x 32 floats = 88 DMA slots of 16 B, deposited by two whole waves (128 slots)
     static constexpr int CPITCH = BN * 4 + 16;
     static constexpr int IPP = (TN >= 3 && TM >= 2) ? (TM + 1) / 2 : TM;   // row blocks per output pass
-    static constexpr int stage(int n16p) { return n16p * 32 + PARB + BN * 128; }
+    static constexpr int stage(int n16p) { return n16p * 32 + PARB; }
     static constexpr int lds(int n16p, int db) {
         const int r = (db ? 2 : 1) * stage(n16p) + BM * 128, ct = IPP * 16 * CPITCH;
         return (r > ct ? r : ct) + 64;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
 #define XB_STAMP(k)
 #endif
     XB_STAMP(0)
-    const int STG = a.n16p * 32 + C::PARB + a.bt_bytes;
+    const int STG = a.n16p * 32 + C::PARB;
     unsigned char *A = xsm + (a.db ? 2 : 1) * STG;
     float *sf = reinterpret_cast<float *>(xsm + a.lds_bytes - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
     uint32_t *smax = reinterpret_cast<uint32_t *>(sf + 8);
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
     const int fr = lane & 15, fq = lane >> 4, nl4 = fq * 4;
     // BatchNorm scale / bias of this lane's output channels: requested first, used last (narrow tiles only: 12 float4 pairs of a
     // 384-wide tile would cost the second workgroup per CU its registers)
-    constexpr bool EARLY_SB = TN <= 2;
+    constexpr bool EARLY_SB = TN <= 1;
     float4 sc[TN], bs[TN];
     if constexpr (EARLY_SB) {
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         const int k = i + rot;
         return k >= a.nk ? k - a.nk : k;
     };
-    const uint32_t wbase = (uint32_t)(n0 >> 4) * 2048u + lane * 16u, wstep = (uint32_t)a.nslab * 2048u;
+    const uint32_t wstep = (uint32_t)a.nslab * 2048u;
     auto dma_patch = [&](int it_) {                               // patch + depthwise parameters of loop step it_
         const int ks = kstep(it_);
         unsigned char *HI = xsm + ((a.db & it_) & 1) * STG, *LO = HI + a.n16p * 16, *PARb = HI + a.n16p * 32;
@@ -259,23 +259,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp, (lds_ptr_t)(PARb + wid * 1024), 16, op, 0, 0, 0);
         }
     };
-    auto dma_b = [&](int it_) {                                   // pointwise weight tile of loop step it_
-        const int ks = kstep(it_);
-        unsigned char *Bs = xsm + ((a.db & it_) & 1) * STG + a.n16p * 32 + C::PARB;
-        const uint32_t ws = wbase + (uint32_t)ks * wstep;
-#pragma unroll
-        for (int it = 0; it < (BN / 16 * 2 + 3) / 4; ++it) {
-            const int pc = it * 4 + wid;
-            if (pc * 1024 < a.bt_bytes) {
-                const uint32_t ob = ws + (uint32_t)pc * 1024u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(Bs + pc * 1024), 16, ob, 0, 0, 0);
-            }
-        }
-    };
-    if (!X_DBG(a, 1)) {
-        dma_patch(0);
-        if (a.db) dma_b(0);
-    }
+    if (!X_DBG(a, 1)) dma_patch(0);
     if constexpr (STEM) {
         // ---- the patch of the depthwise input = the stem conv's output on (PH x PW) positions, straight from the frames.
         // (1) the frame window those positions need, normalised (`img / np.max(img)`, tools/utils.py:405), as fp32 in LDS (the A tile's
@@ -395,15 +379,21 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(3) }
-        if (a.db) {                                                   // the other stage is free: request all of step ks+1 now
-            if (ks + 1 < nk) {
-                dma_patch(ks + 1);
-                dma_b(ks + 1);
+        if (a.db && ks + 1 < nk) dma_patch(ks + 1);                    // the other stage is free: request the patch of step ks+1 now
+        // The pointwise weights of this step.  Wave w multiplies ITS 16 * TN output channels and nobody else's, so a weight tile in LDS
+        // would be written once and read once by one wave: the fragments go from global memory straight into that wave's registers
+        // (host order = fragment order: one coalesced 1 KB load per 16-channel block and half), requested here, used after the depthwise
+        // pass.  No LDS stage for them: 6 - 24 KB less per workgroup, which is what lets a fourth workgroup onto a CU.
+        half8 wh[TN], wl[TN];
+        if (wave_live && !X_DBG(a, 16)) {
+            const uint32_t ws = (uint32_t)(n0 >> 4) * 2048u + (uint32_t)kstep(ks) * wstep + (uint32_t)(wid * TN) * 2048u + (uint32_t)foff;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wh[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsw, ws + (uint32_t)j * 2048u, 0, 0));
+                wl[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsw, ws + (uint32_t)j * 2048u + 1024u, 0, 0));
             }
-        } else {
-            dma_b(ks);
         }
-        const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16, *Bs = HI + a.n16p * 32 + C::PARB;
+        const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16;
         // the parameter slice is read as DWORDS, like the patch: a float-typed LDS read makes the compiler wait for every LDS-DMA in
         // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
         const unsigned char *PARB_ = HI + a.n16p * 32;
@@ -483,25 +473,19 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                 *reinterpret_cast<half8 *>(dst + GL * 256) = lo;
             }
         if (ks == 0) { XB_STAMP(4) }
-        if (a.db) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (step ks+1 stays in flight)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                 // the A tile is complete (single stage: the weight tile has landed, the patch is free)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the weight fragments - and, with two stages, step ks+1 - stay in flight)
+        __builtin_amdgcn_s_barrier();                                 // the A tile is complete (single stage: the patch is free)
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(5) }
         if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile (a wave whose 16*TN channels all lie past N - the last quarter of a 48- or 96-channel
         // layer in a 64- / 128-wide tile - has nothing to multiply nor, below, to stage)
         if (wave_live && !X_DBG(a, 16)) {
-            half8 xh[TM], xl[TM], wh[TN], wl[TN];
+            half8 xh[TM], xl[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 xh[i] = *reinterpret_cast<const half8 *>(A + i * (GL * 512) + afoff);
                 xl[i] = *reinterpret_cast<const half8 *>(A + i * (GL * 512) + GL * 256 + afoff);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                wh[j] = *reinterpret_cast<const half8 *>(Bs + ((wid * TN + j) * 2) * 1024 + foff);
-                wl[j] = *reinterpret_cast<const half8 *>(Bs + ((wid * TN + j) * 2 + 1) * 1024 + foff);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
