@@ -1165,13 +1165,20 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
     const int force_tw = mine && yk_dev_env("YK_XB_TW") ? atoi(yk_dev_env("YK_XB_TW")) : 0;
     const int force_db = mine && yk_dev_env("YK_XB_DB") ? atoi(yk_dev_env("YK_XB_DB")) : -1;
     const bool forced = force_tm || force_tn || force_tw || force_db >= 0;
-    const int tn_want = std::min(3, (g.N + 63) / 64);
+    // N tile: the whole N up to 192 channels.  A long channel walk to 384 outputs (14x20x384 -> 384: 12 steps) takes all 384 in one
+    // workgroup: two 192-wide workgroups would each repeat the depthwise pass, and with four batches in flight what counts is the work,
+    // not the launch's own time (41.2 against 36.8 us alone, +3.5 % images/s in flight).  The 6-step 192 -> 384 block stays at 192 (30 vs 22 us).
+    const bool wide = g.N > 192 && g.nk > 6;
+    const int tn_want = (wide && yk_dev_env("YK_XB_TNL")) ? atoi(yk_dev_env("YK_XB_TNL")) : (wide ? 6 : std::min(3, (g.N + 63) / 64));
     (void)max_batch;
     for (int tm : g_xb_tm)
         for (int tn : g_xb_tn) {
             if (!xb_has(tm, tn) || (force_tm && tm != force_tm) || (force_tn && tn != force_tn)) continue;
             if (!force_tn && tn != tn_want) continue;
-            if (!force_tm && tm > (tn_want == 1 ? 8 : 4)) continue;      // measured: 64-pixel tiles from 96 output channels on, 128 below
+            // measured: 64-pixel tiles from 96 output channels on, 128 below.  (The 12-step blocks at 14x20x384 alone are faster on 32-pixel
+            // tiles - 30.2 against 36 us - but with four batches in flight the step loses 3 %: more workgroups, more halo, more contention)
+            const int tm_long = yk_dev_env("YK_XB_TML") ? atoi(yk_dev_env("YK_XB_TML")) : 4;
+            if (!force_tm && tm > (tn_want == 1 ? 8 : (g.nk > 6 ? tm_long : 4))) continue;
             const int bm = 16 * tm;
             for (int TW = 1; TW <= std::min(g.Wo, bm); ++TW) {
                 if (force_tw && TW != force_tw) continue;
@@ -1183,7 +1190,7 @@ bool xb_geometry(xb_args &g, int *tm_out, int *tn_out, unsigned *lds_out, int ma
                 for (int db = 0; db <= 1; ++db) {
                     if (force_db >= 0 ? db != force_db : db != 0) continue;
                     const unsigned lds = xb_lds(tm, tn, n16p, db, g.N);
-                    if (lds > 160 * 1024 || (!forced && xb_lds(tm, tn, n16p, db, g.N, true) > 53 * 1024 + 512)) continue;
+                    if (lds > 160 * 1024 || (!forced && xb_lds(tm, tn, n16p, db, g.N, !wide) > 53 * 1024 + 512)) continue;
                     const long tiles = (long)((g.Ho + TH - 1) / TH) * ((g.Wo + TW - 1) / TW);
                     const double cover = (double)g.Ho * g.Wo / ((double)tiles * bm);       // useful rows of the MFMA tiles
                     const double halo = (double)TH * TW * s * s / ((double)PH * PW);       // bytes used / bytes staged

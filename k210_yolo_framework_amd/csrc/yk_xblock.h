@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         __builtin_amdgcn_s_barrier();                                 // everybody's have; mma(ks-1) is over: A and the weight tile are free
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(3) }
-        if (a.db && ks + 1 < nk) dma_patch(ks + 1);                    // the other stage is free: request the patch of step ks+1 now
+        if (ks == 1) { XB_STAMP(13) }
         // The pointwise weights of this step.  Wave w multiplies ITS 16 * TN output channels and nobody else's, so a weight tile in LDS
         // would be written once and read once by one wave: the fragments go from global memory straight into that wave's registers
         // (host order = fragment order: one coalesced 1 KB load per 16-channel block and half), requested here, used after the depthwise
@@ -393,6 +393,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                 wl[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsw, ws + (uint32_t)j * 2048u + 1024u, 0, 0));
             }
         }
+        // two stages: the other one is free - request the patch of step ks+1 now (AFTER the weight loads: the memory counter retires in
+        // order, and the weights are needed first)
+        if (a.db && ks + 1 < nk) dma_patch(ks + 1);
         const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16;
         // the parameter slice is read as DWORDS, like the patch: a float-typed LDS read makes the compiler wait for every LDS-DMA in
         // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
@@ -473,10 +476,12 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                 *reinterpret_cast<half8 *>(dst + GL * 256) = lo;
             }
         if (ks == 0) { XB_STAMP(4) }
+        if (ks == 1) { XB_STAMP(14) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the weight fragments - and, with two stages, step ks+1 - stay in flight)
         __builtin_amdgcn_s_barrier();                                 // the A tile is complete (single stage: the patch is free)
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(5) }
+        if (ks == 1) { XB_STAMP(15) }
         if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile (a wave whose 16*TN channels all lie past N - the last quarter of a 48- or 96-channel
         // layer in a 64- / 128-wide tile - has nothing to multiply nor, below, to stage)

@@ -46,5 +46,8 @@ for li in range(first, last + 1):
         if '+conv1x1' in names[i] and f',{2 if db else 1}stage' in names[i]:
             rows.append((float(ms[i]) * 1e3, names[i], tm, tn, tw, db))
     rows.sort()
+    if os.environ.get('XBS_ALL'):
+        for t, n, tm, tn, tw, db in rows:
+            print(f'   {t:6.1f} us  tm{tm} tn{tn} tw{tw} db{db}  {n.split("[")[1][:-1]}')
     print(f'block {li} {names0[dw0[li]]} + {names0[dw0[li] + 1]}: unfused {unf:.1f} us | ' +
           ' | '.join(f'{t:.1f} tm{tm} tn{tn} {n.split("[")[1][:-1]}' for t, n, tm, tn, tw, db in rows[:5]), flush=True)

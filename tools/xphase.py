@@ -1,6 +1,6 @@
 """Dev tool: per-workgroup phase timestamps of one fused block launch of the f16x2 plan (wall_clock64 ticks, 100 MHz -> 10 ns).
 
-    python tools/xphase.py <launch index> [B]
+    python tools/xphase.py <launch index>[,<launch index>...] [B]        (XPH_SCHEDULE=throughput: the plan bench.py's `value` runs)
 """
 import ctypes as C
 import os
@@ -12,7 +12,7 @@ from k210_yolo_framework_amd import engine, netspec as ns
 
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
-plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=B, precision='f16x2')
+plan = engine.Plan(spec, spec.init_weights(seed=1), max_batch=B, precision='f16x2', schedule=os.environ.get('XPH_SCHEDULE', 'latency'))
 frames = torch.randint(0, 256, (B, 224, 320, 3), dtype=torch.uint8, device='cuda')
 for _ in range(3):
     plan.run_u8(frames)
@@ -36,6 +36,10 @@ for li in [int(v) for v in sys.argv[1].split(',')]:
                                                                                np.median(d[:, k] - d[:, k - 1])))
     if v[:, 11].max() > 0:
         print('  stem: window loads issued+stored %.2f us, barrier %.2f us, patch done (stamp 1) %.2f us' % (np.median(d[:, 11]), np.median(d[:, 12]), np.median(d[:, 1])))
+    if v[:, 13].max() > 0:                                        # steady-state step (the second one)
+        print('  step 1: top (bar1) %.2f us | dw %.2f | bar2 %.2f   (step 0: bar1 %.2f | dw %.2f | bar2 %.2f; step 0 bar2 -> step 1 bar1 = mma + wait %.2f)' % (
+            np.median(d[:, 13]), np.median(d[:, 14] - d[:, 13]), np.median(d[:, 15] - d[:, 14]), np.median(d[:, 3]), np.median(d[:, 4] - d[:, 3]),
+            np.median(d[:, 5] - d[:, 4]), np.median(d[:, 13] - d[:, 5])))
     st = (v[:, 0] - t0) / 100.0
     print('  WG start times: median %.2f p90 %.2f max %.2f us' % (np.median(st), np.percentile(st, 90), st.max()))
 plan.close()
