@@ -440,9 +440,17 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                     float2v d2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
+#if defined(YK_KO) && (YK_KO & 2)                                     // pricing build: three patch reads (one per row) instead of nine
+                        const int at = (base + ((t / 3) * a.PW) * GL) * 16;
+#else
                         const int at = (base + ((t / 3) * a.PW + (t % 3)) * GL) * 16;
+#endif
                         const u32x4 h = *reinterpret_cast<const u32x4 *>(HI + at), l = *reinterpret_cast<const u32x4 *>(LO + at);
+#if defined(YK_KO) && (YK_KO & 1)                                     // pricing build (wrong results on purpose): no weight reads
+                        const u32x4 w0 = {0x3f000000u, 0x3e800000u, 0x3f000000u, 0x3e800000u}, w1 = w0;
+#else
                         const u32x4 w0 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8) * 4), w1 = *reinterpret_cast<const u32x4 *>(PARB_ + (t * 32 + q * 8 + 4) * 4);
+#endif
                         const float2v w2[4] = {{__uint_as_float(w0[0]), __uint_as_float(w0[1])}, {__uint_as_float(w0[2]), __uint_as_float(w0[3])},
                                                {__uint_as_float(w1[0]), __uint_as_float(w1[1])}, {__uint_as_float(w1[2]), __uint_as_float(w1[3])}};
                         if (f32patch) {                               // (h, l) are the fp32 planes: channels 0-3 | 4-7
