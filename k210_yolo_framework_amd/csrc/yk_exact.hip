@@ -49,7 +49,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
 
-__device__ __forceinline__ float x_actf(float v, float slope, float cap) { return fminf(fmaxf(v, v * slope), cap); }
+// activation min(max(v, v * slope), cap) as ONE median: for slope in [0, 1] and cap >= 0 the three values are ordered (v * slope, v, cap)
+// or (v, v * slope, cap) - or cap sits below v - and the median is the clamped value (leaky / linear layers have cap = +inf, ReLU6 slope 0)
+__device__ __forceinline__ float x_actf(float v, float slope, float cap) { return __builtin_amdgcn_fmed3f(v, v * slope, cap); }
 __device__ __forceinline__ uint32_t x_div(uint32_t n, yk_fastdiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
 
 // exponent e with bound * 2^-e in [2^13, 2^14); bound given as float bits (0 / inf / nan -> e = 0)

@@ -162,7 +162,7 @@ __device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float u = __builtin_fmaf(acc[nf][k], scv[nf][k], bsv[nf][k]);
-                v[k] = inside ? fminf(fmaxf(u, u * a.st_slope), cap) : 0.f;
+                v[k] = inside ? x_actf(u, a.st_slope, cap) : 0.f;
             }
             // the patch of a fused stem is fp32: [position][4 groups][channels 0-3] in the first plane, [..][channels 4-7] in the second (what
             // the depthwise taps multiply; round 3 stored (hi | lo) here and every tap converted them back, 72 VALU operations per item)
@@ -223,12 +223,15 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
     uint32_t poff[PQ];
 #pragma unroll
     for (int i = 0; i < PQ; ++i) {
-        const uint32_t q = (uint32_t)(i * 256 + tid);
-        const uint32_t pos = q >> 2, g4 = q & 3;
-        const uint32_t r = x_div(pos, a.fd_pw), c = pos - r * a.PW;
-        const int iy = iy0 + (int)r, ix = ix0 + (int)c;
-        const bool ok = (int)q < a.n16 && (unsigned)iy < (unsigned)a.in.H && (unsigned)ix < (unsigned)a.in.W;
-        poff[i] = ok ? (uint32_t)(((iy * a.in.W + ix) * G + (int)g4) * 32) : X_OOB;
+        poff[i] = X_OOB;
+        if (!STEM && i * 256 < a.n16p) {                              // (uniform: a small patch skips the slots it does not have)
+            const uint32_t q = (uint32_t)(i * 256 + tid);
+            const uint32_t pos = q >> 2, g4 = q & 3;
+            const uint32_t r = x_div(pos, a.fd_pw), c = pos - r * a.PW;
+            const int iy = iy0 + (int)r, ix = ix0 + (int)c;
+            const bool ok = (int)q < a.n16 && (unsigned)iy < (unsigned)a.in.H && (unsigned)ix < (unsigned)a.in.W;
+            poff[i] = ok ? (uint32_t)(((iy * a.in.W + ix) * G + (int)g4) * 32) : X_OOB;
+        }
     }
     const int g4l = tid & 3;
     // Workgroups walk the channel steps from different starting points (a function of the tile's place in ITS image only, so an
