@@ -506,7 +506,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)                        // (a fused-stem block has ONE step: its first product starts from the zero constant)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], STEM ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -545,13 +546,16 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         // pieces per lane, which is why that form is staged through LDS below; here the staging would be 33 KB written + 33 KB read on
         // the launch's busiest unit, a barrier and a copy-out loop for nothing.)
         if (wave_live) {
+            // one descriptor per image (scalar), 32-bit offsets inside it: the stores need no 64-bit address arithmetic per lane
+            const uint32_t oimg = (uint32_t)a.Ho * a.Wo * a.outG * 32u;
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)b * oimg), 0, oimg, 0x00020000);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int p = i * 16 + fr;
                 const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
                 const int oy = oy0 + py, ox = ox0 + px;
                 const bool mok = py < a.TH && oy < a.Ho && ox < a.Wo;
-                const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+                const uint32_t po = (uint32_t)((oy * a.Wo + ox) * a.outG) * 32u;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + (wid * TN + j) * 16 + nl4;
@@ -563,8 +567,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                     if (mok && (n >> 3) < a.outG) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) rmax = fmaxf(rmax, fabsf(v[k]));
-                        *reinterpret_cast<u32x4 *>(a.out + (m * a.outG + (n >> 3)) * 32 + ((n >> 2) & 1) * 16) =
-                            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rso,
+                                                               po + (uint32_t)((n >> 3) * 32 + ((n >> 2) & 1) * 16), 0, 0);
                     }
                 }
             }

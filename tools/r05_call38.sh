@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5, call 37: activation as one median instruction, absent patch slots skipped (shipped build: f16x2 tests + bench twice)
+# round 5, call 38: direct epilogue through a per-image buffer descriptor (32-bit offsets), zero-constant first product in the stem block
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r5c37; mkdir -p $O
+O=gpurun_out/r5c38; mkdir -p $O
 ( timeout 1200 python -m pytest tests/test_gpu_net.py tests/test_gpu_layers.py tests/test_gpu_e2e.py tests/test_gpu_heads.py tests/test_gpu_persist.py -q -x -m gpu ) > $O/tests.log 2>&1; tail -2 $O/tests.log
 for i in 1 2; do
 ( timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary ) > $O/bench_$i.json 2> $O/bench_$i.err; python -c "
