@@ -1035,6 +1035,7 @@ struct xlaunch {
     int cfg = 0, ns = 2;               // xg_kernel tile configuration and ring depth
     unsigned lds = 0;
     int in_tid = -1, out_tid = -1;     // tensors of a plain depthwise / 1x1 conv launch (chain detection of the persistent stage)
+    unsigned ring_lds = 0;             // fused block: dynamic LDS without the output staging area
     xp_args pa;                        // XK_PERSIST
     xh_args ha;                        // XK_HEADS
     unsigned h_lds = 0;
@@ -1148,10 +1149,10 @@ int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hi
 // The pointwise weights are NOT staged (each wave loads its own fragments into registers): `wt` adds the tile they used to take, which
 // is what the tile-selection rule below was measured with (rounds 3-4) and still uses, so that the tiles stay the measured ones
 int xb_bt_bytes(int tn, int N) { return std::min(64 * tn, (N + 15) / 16 * 16) * 128; }
-unsigned xb_lds(int tm, int tn, int n16p, int db, int N, bool wt = false) {
+unsigned xb_lds(int tm, int tn, int n16p, int db, int N, bool wt = false, bool staged = true) {
     const int bm = 16 * tm, bn = 64 * tn;
     const int ipp = (tn >= 3 && tm >= 2) ? (tm + 1) / 2 : tm;
-    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + (wt ? xb_bt_bytes(tn, N) : 0)) + bm * 128, ct = ipp * 16 * (bn * 4 + 16);
+    const int ring = (db ? 2 : 1) * (n16p * 32 + 2048 + (wt ? xb_bt_bytes(tn, N) : 0)) + bm * 128, ct = staged ? ipp * 16 * (bn * 4 + 16) : 0;
     return (unsigned)(std::max(ring, ct) + 64);
 }
 // Tile geometry of a fused block.  Measured on K2 at B=32 (tools/xbsweep.py: every (TM, TN, tile width, stages) per block): the launch
@@ -1668,7 +1669,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     struct xfuse {
         xb_args g;
         int tm = 0, tn = 0;
-        unsigned lds = 0;
+        unsigned lds = 0, ring = 0;    // dynamic LDS with / without the output staging area
     };
     std::vector<int> dw_of(n_ops, -1);
     std::vector<xfuse> fuse(n_ops);
@@ -1702,6 +1703,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             const int min_px = yk_dev_env("YK_XB_MINPX") ? atoi(yk_dev_env("YK_XB_MINPX")) : 128;
             if ((f.g.Ho * f.g.Wo < min_px || f.g.nk > max_nk) && !yk_dev_env("YK_XB_ALWAYS")) continue;
             if (!xb_geometry(f.g, &f.tm, &f.tn, &f.lds, max_batch, n_fused_seen++)) continue;
+            f.ring = xb_lds(f.tm, f.tn, f.g.n16p, f.g.db, f.g.N, false, false);
             dw_of[i + 1] = i;
             skip[i] = 1;
             gone[y] = 1;
@@ -1732,6 +1734,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             f.g.n16 = n16; f.g.n16p = n16p;
             f.g.lds_bytes = (int)lds;
             f.lds = lds;
+            f.ring = (unsigned)(ring + 64);
             stem_of[i + 2] = i;
             skip[i] = 1;
             gone[y] = 1;
@@ -1920,6 +1923,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             l.tm = fuse[i].tm;
             l.tn = fuse[i].tn;
             l.lds = fuse[i].lds;
+            l.ring_lds = fuse[i].ring;
             xb_args &g = l.b;
             g = fuse[i].g;
             const int co = o[YK_F_COUT], cin = o[YK_F_CIN];
@@ -2069,11 +2073,14 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 // flight 2 stages are +3.5 % on the whole step (tools/sweep3.sh): 48 KB less LDS per workgroup lets another stream's
                 // kernel onto the CU.)
                 l.ns = nsteps >= (yk_dev_env("YK_X_NS3") ? atoi(yk_dev_env("YK_X_NS3")) : 13) ? 3 : 2;
-                if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 long sk = 1;
                 if (tiles < 384 && nsteps >= 32) sk = std::min<long>(std::min<long>(7, (900 + tiles - 1) / tiles), nsteps / 8);   // measured (tools/xsweep.py): 7 slices at 105 tiles (8: +25 %), 4 at 280 (3: +9 %)
                 if (!yk_env_flag("YK_SPLITK", true)) sk = 1;
                 if (const char *e = yk_dev_env("YK_X_SPLITK")) sk = std::max(1, std::min(atoi(e), nsteps));
+                // a K-split launch is a small grid of long loops (the 3x3 head convs): two stages (32 KB) instead of three leave room on the CU
+                // for the other batches' workgroups - the launch alone takes the same time (62.3 / 63.1 us), four batches in flight gain 1 %
+                if (sk > 1 && !yk_dev_env("YK_X_SK_NS3")) l.ns = 2;
+                if (const char *e = yk_dev_env("YK_X_NS")) l.ns = std::max(2, std::min(4, atoi(e)));
                 g.splitk = (int)std::max<long>(1, sk);
                 if (g.splitk > 1) {
                     void *sl;
@@ -2207,7 +2214,16 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 other = other || (l.kind == XK_BLOCK && l.b.res.p == T.d) || (l.kind == XK_CONV && (l.c.s0.p == T.d || l.c.s1.p == T.d || l.c.res.p == T.d)) ||
                         (l.kind == XK_POOL && l.p.in.p == T.d) || (l.kind == XK_ADD && (l.ad.x.p == T.d || l.ad.y.p == T.d));
             if (other || !prod || !cons) continue;
-            if (prod->kind == XK_BLOCK) prod->b.dst_f32 = 1; else prod->c.dst_f32 = 1;
+            if (prod->kind == XK_BLOCK) {
+                prod->b.dst_f32 = 1;
+                // registers -> global memory, no staging area: the launch asks for the patch + A tile only (a 384-wide tile: 22 KB instead of 50)
+                if (prod->ring_lds && prod->ring_lds < prod->lds && !yk_dev_env("YK_XB_NOSHRINK")) {
+                    prod->lds = prod->ring_lds;
+                    prod->b.lds_bytes = (int)prod->ring_lds;
+                }
+            } else {
+                prod->c.dst_f32 = 1;
+            }
             if (cons->kind == XK_BLOCK) cons->b.src_f32 = 1; else cons->d.in_f32 = 1;
             T.f32 = true;
         }
