@@ -6,21 +6,27 @@
 //
 //   DMA(k)    one burst of `buffer_load ... lds`: the input patch of the step's four channel groups ((TH-1)s+3 x (TW-1)s+3 positions
 //             x 4 groups, hi and lo halves in separate regions; pixels outside the image and groups past the tensor's last one get an
-//             out-of-range offset and arrive as zeros), the step's slice of the depthwise parameter table (nine taps, scale, bias x
-//             32 channels fp32) and the pointwise weight tile [BN][32] (hi | lo, host order)
+//             out-of-range offset and arrive as zeros) and the step's slice of the depthwise parameter table (nine taps, scale, bias x
+//             32 channels fp32)
+//   W(k)      the pointwise weight fragments of the step, global memory -> REGISTERS of the wave that multiplies them (wave w owns
+//             output channels [w*16*TN, (w+1)*16*TN): a weight tile in LDS would be written once and read once by one wave; host order =
+//             fragment order, one coalesced 1 KB load per 16-channel block and half).  Round 5: this took 6 - 24 KB per workgroup out of
+//             LDS - a fourth workgroup per CU, and N = 384 in one workgroup
 //   dw(k)     one thread = one (pixel, channel group): nine taps from LDS; hi + lo back in fp32 by one mixed-precision op per channel,
 //             packed fp32 FMAs on channel pairs, BN + activation, scaled by the MIDDLE exponent and split pair-wise into (hi, lo)
 //             straight into the MFMA A tile - the depthwise tensor never exists in HBM
 //   mma(k)    A x B on v_mfma_f32_16x16x32_f16, three products per tile
 //
 // Single-buffered and phase-shifted (two s_barriers per step): the patch of step k+1 is requested when dw(k) is over and lands under
-// mma(k); the weight tile of step k is requested when mma(k-1) is over and lands under dw(k).  One stage of everything keeps the
-// workgroup at <= 53 KB (tiles of 64 pixels x <= 192 channels or 128 pixels x 64 channels: xb_geometry), so THREE workgroups share a CU
-// and their DMA, depthwise (VALU) and MFMA phases overlap; the launches are bound by VALU issue (profiles/r03_x2_step_pmc.json).  The
-// output tile leaves through LDS in passes of IPP row blocks.  The depthwise tensor's maximum is never measured, so its exponent comes
-// from its bound (gain_dw * amax(in) + off_dw) and the pointwise bound is built on that bound; the two levels of over-estimate
-// (2^3 x 2^7 in these networks) stay far inside fp16's exponent range (see the header of yk_exact.hip).  STEM: the depthwise input is
-// the network's first conv, computed in the kernel from the frame window (xb_stem_patch).
+// mma(k); the weight fragments of step k are requested before dw(k).  One stage of patch + A tile is 23 - 39 KB and the small tiles are
+// held to 128 registers, so FOUR workgroups share a CU and their DMA, depthwise (VALU) and MFMA phases overlap - co-residency is what
+// these launches' time follows (round 5: 3 -> 4 workgroups = -8 ... -15 %; two stages, which halve it, never paid; removing the depthwise
+// pass's LDS reads in a pricing build changes nothing).  The output tile leaves through LDS in passes of IPP row blocks, or - fp32
+// outputs - straight from the registers through a per-image buffer descriptor.  The depthwise tensor's maximum is never measured, so its
+// exponent comes from its bound (gain_dw * amax(in) + off_dw) and the pointwise bound is built on that bound; the two levels of
+// over-estimate (2^3 x 2^7 in these networks) stay far inside fp16's exponent range (see the header of yk_exact.hip).  STEM: the
+// depthwise input is the network's first conv, computed in the kernel from the frame window (xb_stem_patch); its patch and A tile hold
+// the GL channel groups the stem has (three for 24 filters).
 #pragma once
 
 struct xb_args {
