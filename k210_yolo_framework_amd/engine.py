@@ -499,6 +499,7 @@ class Pipeline:
             self.slots.append(s)
         self._n = 0
         self.host_us = 0.0
+        self._copy_stream = None                                                        # submit_host: the H2D leg's own stream (created on first use)
 
     # -- buffers ------------------------------------------------------------------------------------
     def input(self, i: int):
@@ -523,20 +524,55 @@ class Pipeline:
             s.h_offsets, s.d_offsets = _pinned((self.max_batch + 1,), torch.int32)
             s.h_index, s.d_index = _pinned((nrow,), torch.int32)
             s.h_offsets.zero_()
+            # the frames of a host batch land in one of TWO device buffers, copied on the pipeline's copy stream: the copy of this slot's
+            # next batch runs under its current batch's kernels instead of in front of them on the same stream (round 5: the copy leg is
+            # 125 us of a 330 us step, and a stream that copies is a stream that does not compute - from host 0.87 of resident before)
+            s.h2d_bufs = [s.src, torch.full_like(s.src, 127)]
+            s.h2d_next = 0
+            s.h2d_copied = [torch.cuda.Event(), torch.cuda.Event()]
+            s.h2d_free = [None, None]
+            if self._copy_stream is None:
+                if self._own_streams:                                   # library-created, like the slots' streams
+                    h = C.c_void_p()
+                    with torch.cuda.device(s.src.device):
+                        _check(lib().yk_stream_create(C.byref(h), C.c_int(0)), 'yk_stream_create')
+                    self._own_streams.append(h)
+                    self._copy_stream = torch.cuda.ExternalStream(h.value, device=s.src.device)
+                else:
+                    self._copy_stream = torch.cuda.Stream(device=s.src.device)
 
     # -- the step, as the library calls it is made of (eager, or recorded by capture()) ---------------------------------
     def _h2d(self, s, B):
         """The host -> device leg, issued EAGERLY in front of the replay (measured, images/s from host with four batches in flight: copy
         engine in front of the replay 66 k; as a copy node inside the captured step 55 k; as a kernel inside it that reads the pinned
-        frames through their device alias 54 k; everything eager 74 k - profiles/r04_schedules.txt)."""
-        _check(lib().yk_memcpy_async(C.c_void_p(s.src.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()), s.st),
-               'yk_memcpy_async')
+        frames through their device alias 54 k; everything eager 74 k - profiles/r04_schedules.txt) - and, since round 5, on the pipeline's
+        COPY stream into the slot's other input buffer: it waits for the batch that last read that buffer, the slot's stream waits for it.
+        -> the device address the step reads."""
+        b = s.h2d_next
+        s.h2d_next ^= 1
+        dst, cs = s.h2d_bufs[b], self._copy_stream
+        if s.h2d_free[b] is not None:
+            # the batch that last read this buffer (two submits of this slot ago) - waited for on the HOST, where it is over long ago in steady
+            # state: a wait inside the copy stream would put barrier packets into a fifth hardware queue, and a fifth active queue costs the
+            # four compute streams a quarter of their rate (DESIGN.md 0.0: the part has four compute pipes; measured 85 -> 61 k images/s)
+            s.h2d_free[b].synchronize()
+        _check(lib().yk_memcpy_async(C.c_void_p(dst.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()),
+                                     C.c_void_p(cs.cuda_stream)), 'yk_memcpy_async')
+        s.h2d_copied[b].record(cs)
+        s.stream.wait_event(s.h2d_copied[b])
+        s.h2d_last = b
+        return dst.data_ptr()
+
+    def _h2d_done(self, s):
+        """After the step has been given to the slot's stream: its input buffer is free once the stream gets here."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(s.stream)
+        s.h2d_free[s.h2d_last] = ev
 
     def _issue(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
         L = lib()
         H, W = self.spec.in_hw
-        if host:
-            src_ptr = s.src.data_ptr()
         x = src_ptr
         if self.src_hw:
             _check(L.yk_letterbox_u8(C.c_void_p(x), C.c_int(B), C.c_int(self.src_hw[0]), C.c_int(self.src_hw[1]), _ptr(s.frames),
@@ -561,11 +597,14 @@ class Pipeline:
     def _run(self, s, B, src_ptr, host, use_hw, obj, iou, max_out, want_index):
         if max_out > self.max_out:
             raise YkError(f'max_out {max_out} > the pipeline\'s max_out {self.max_out}')
-        args = (B, src_ptr, host, use_hw, float(obj), float(iou), int(max_out), bool(want_index))
         if host:
-            self._h2d(s, B)
+            src_ptr = self._h2d(s, B)
+        args = (B, src_ptr, host, use_hw, float(obj), float(iou), int(max_out), bool(want_index))
         if not self.graph:
-            return self._issue(s, *args)
+            self._issue(s, *args)
+            if host:
+                self._h2d_done(s)
+            return
         # a captured step holds the address of the stream's decode scratch: if that buffer has moved since (it cannot once the slot is
         # warm - __init__ sizes it for max_batch x max_out - but another user of the same stream could grow it), every capture is stale
         gen = int(lib().yk_scratch_generation(s.st))
@@ -582,6 +621,8 @@ class Pipeline:
             g = capture(s.st, lambda: self._issue(s, *args))
         s.graphs[args] = g                                         # (re-)inserted last = most recently used
         g.launch(s.st)
+        if host:
+            self._h2d_done(s)
 
     def _warm(self, s, host):
         """One eager step at the slot's LARGEST shape (max_batch images, max_out rows per class, box indices on) for each result form the
@@ -592,7 +633,7 @@ class Pipeline:
             self._issue(s, B, s.src.data_ptr(), False, False, 0.7, 0.5, self.max_out, True)
             s.warm_dev = did = True
         if host and not s.warm_host:
-            self._issue(s, B, None, True, False, 0.7, 0.5, self.max_out, True)
+            self._issue(s, B, s.src.data_ptr(), True, False, 0.7, 0.5, self.max_out, True)
             s.warm_host = did = True
         if did:
             s.stream.synchronize()
@@ -660,7 +701,8 @@ class Pipeline:
             f = torch.as_tensor(frames_u8)
             assert f.dtype == torch.uint8 and tuple(f.shape[1:]) == tuple(s.src.shape[1:]), f.shape
             B = int(f.shape[0])
-            s.stream.synchronize()                                      # the slot's previous batch may still be reading h_src
+            for ev in s.h2d_copied:                                     # the slot's previous copies may still be reading h_src
+                ev.synchronize()
             s.h_src[:B].copy_(f)
         assert 0 < B <= self.max_batch
         use_hw = self._set_hw(s, B, image_hw)
@@ -677,6 +719,9 @@ class Pipeline:
             p.raise_if_failed()
 
     def close(self):
+        if self._copy_stream is not None:
+            self._copy_stream.synchronize()
+            self._copy_stream = None
         for s in self.streams:
             s.synchronize()
         for s in self.slots:

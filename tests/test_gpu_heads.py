@@ -97,6 +97,13 @@ def test_schedules_select_the_launch_form_and_agree():
             names = [l[0] for l in plan.launches()]
             cluster = [n for n in names if n.startswith('x:persist') or n.startswith('x:heads')]
             assert len(cluster) == (2 if sched == 'latency' else 0), names
+            if sched == 'throughput':
+                # the five 14x20x384 blocks are ONE launch each there, all 384 output channels in one workgroup (one depthwise pass); the two
+                # 7x10 blocks stay depthwise + 1x1 launches; the K-split 3x3 head convs run on two ring stages
+                wide = [n for n in names if 'dw3x3s1+conv1x1_384to384' in n]
+                assert len(wide) == 5 and all(',384ch,' in n for n in wide), names
+                assert sum(n.startswith('x:dw3x3s') and '+conv' not in n for n in names) == 2, names
+                assert all('ring2' in n for n in names if 'splitk' in n), names
             plan.run_u8(f)
             plan.check()
             outs[sched] = [o[:5].cpu().numpy().copy() for o in plan.outputs()]
