@@ -43,6 +43,11 @@ struct igemm_args {
     int ks, stride, pad_t, pad_l;
     int M, N, K;                // M = B*Ho*Wo, N = Cout, K = ks*ks*(c0p+c1p)
     const yk_half *w;           // [N][K]
+    // the same weights in MFMA-fragment order [K/64 steps][ceil(N/16) blocks][2 half-steps][64 lanes][8] (null unless the plan was built
+    // for the register-fragment ring kernel, yk_igemm_br.h): a wave's load of one block and half-step is 1 KB of contiguous memory
+    const yk_half *wfrag;
+    uint32_t wfrag_bytes;
+    int nb16;
     const float *scale, *bias;  // [N]
     int act;
     float alpha;

@@ -392,6 +392,24 @@ extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops,
             if ((rc = upload(p, &dwt, w.data(), w.size() * 2))) return fail(rc);
             g.w = (const yk_half *)dwt;
             g.w_bytes = (uint32_t)(w.size() * 2);
+            g.wfrag = nullptr; g.wfrag_bytes = 0; g.nb16 = (co + 15) / 16;
+            if (g.K % 64 == 0 && yk_env_flag("YK_PIPE_BR", false)) {     // fragment-order copy for yk_igemm_br.h (experiment switch)
+                const int nb = g.nb16, nsteps = g.K / 64;
+                std::vector<uint16_t> wf((size_t)nsteps * nb * 1024, 0);
+                for (int st = 0; st < nsteps; ++st)
+                    for (int b = 0; b < nb; ++b)
+                        for (int hs = 0; hs < 2; ++hs)
+                            for (int ln = 0; ln < 64; ++ln) {
+                                const int n = b * 16 + (ln & 15), k0 = st * 64 + (hs * 4 + (ln >> 4)) * 8;
+                                if (n >= co) continue;
+                                for (int e = 0; e < 8; ++e)
+                                    wf[(((size_t)st * nb + b) * 2 + hs) * 512 + (size_t)ln * 8 + e] = w[(size_t)n * g.K + k0 + e];
+                            }
+                void *dfr;
+                if ((rc = upload(p, &dfr, wf.data(), wf.size() * 2))) return fail(rc);
+                g.wfrag = (const yk_half *)dfr;
+                g.wfrag_bytes = (uint32_t)(wf.size() * 2);
+            }
             if ((rc = upload_sb(p, blob, o[YK_F_SCALE_OFF], co, &g.scale))) return fail(rc);
             if ((rc = upload_sb(p, blob, o[YK_F_BIAS_OFF], co, &g.bias))) return fail(rc);
             g.act = o[YK_F_ACT]; g.alpha = alpha;

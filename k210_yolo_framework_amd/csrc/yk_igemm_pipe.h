@@ -20,10 +20,7 @@
 // the row keeps (y0, x0) instead of a precomputed pointer.
 #pragma once
 
-template <int N>
-__device__ __forceinline__ void yk_wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
+#include "yk_igemm_br.h"                                           // (the variant with the weight fragments in registers; defines yk_wait_vm_lgkm0)
 
 // IL (round 5): the DMA pieces of the step being prefetched are issued BETWEEN the MFMAs of the step being computed, one piece per few MFMAs
 // (an LDS-DMA instruction costs its wave ~150 cycles of issue when a whole step's pieces go out in one block ahead of the fragment reads,
@@ -328,6 +325,8 @@ static int yk_pipe_phase_split() {
 
 template <int BM, int BN, int WM, int WN, int NS>
 static int launch_pipe(const igemm_args &a, hipStream_t st) {
+    if constexpr (NS == 2 && BM * BN <= 128 * 128)
+        if (!a.up0 && a.wfrag && yk_pipe_br()) return launch_br<BM, BN, WM, WN, NS>(a, st);     // weight fragments in registers (yk_igemm_br.h)
     constexpr size_t ring = (size_t)NS * (BM + BN) * 64 * 2, ct = (size_t)BM * (BN + 8) * 2;
     constexpr size_t ldsd = ring > ct ? ring : ct;
     dim3 g2((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
