@@ -1101,15 +1101,17 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
     return YK_ERR_ARG;
 }
 
-template <int TM, int TN, int SG>
+template <int TM, int TN, int SG, bool F32IN = false>
 int x_launch_b2(const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+    if constexpr (SG > 0 && !F32IN)
+        if (g.in_f32) return x_launch_b2<TM, TN, SG, true>(g, batch, lds, st);
     static unsigned allowed = 64 * 1024;
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN, SG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xb_kernel<TM, TN, SG, F32IN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         allowed = 160 * 1024;
     }
     dim3 grid((unsigned)(batch * g.tiles_x * g.tiles_y), (unsigned)((g.N + 64 * TN - 1) / (64 * TN)));
-    hipLaunchKernelGGL((xb_kernel<TM, TN, SG>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((xb_kernel<TM, TN, SG, F32IN>), grid, dim3(256), lds, st, g);
     return YK_OK;
 }
 template <int TM, int TN>

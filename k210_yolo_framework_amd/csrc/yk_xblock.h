@@ -181,7 +181,9 @@ __device__ __forceinline__ void xb_stem_patch(const xb_args &a, const void *winp
     }
 }
 
-template <int TM, int TN, int SG>                                     // SG: 0 = the input is a stored tensor; 2, 3, 4 = fused stem with SG channel groups
+// SG: 0 = the input is a stored tensor; 2, 3, 4 = fused stem with SG channel groups.  F32IN: the fused stem reads fp32 frames (else u8) - a
+// compile-time choice: with both window loaders in one kernel the stem block kept ~190 scalar registers in vector-register lanes
+template <int TM, int TN, int SG, bool F32IN = false>
 __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb_args a) {   // 2 (3) workgroups per CU: <= 256 (168) registers; the fused-stem block stays under 128 by itself (4 per CU)
     typedef xb_cfg<TM, TN> C;
     constexpr int BM = C::BM, BN = C::BN;
@@ -189,6 +191,13 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
     constexpr int GL = STEM ? SG : 4;                                 // channel groups per patch position and per A row
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = a.in.G, s = a.stride;
+    // two stages and the in-place fp32 prepass exist for the developer sweeps only (both measured slower everywhere): constants in the shipped
+    // kernels, whose code and scalar registers they otherwise cost
+#ifdef YK_DEV
+    const int XB_DB = a.db, XB_PREPASS = a.prepass;
+#else
+    constexpr int XB_DB = 0, XB_PREPASS = 0;
+#endif
 #ifdef YK_DEV
 #define XB_STAMP(k) \
     if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)wall_clock64();
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
 #endif
     XB_STAMP(0)
     const int STG = a.n16p * 32 + C::PARB;
-    unsigned char *A = xsm + (a.db ? 2 : 1) * STG;
+    unsigned char *A = xsm + (XB_DB ? 2 : 1) * STG;
     float *sf = reinterpret_cast<float *>(xsm + a.lds_bytes - 64);   // [0] 2^e_in [1] 2^-e_mid [2] 2^e_mid [3] 2^-e_out [4] 2^e_res
     uint32_t *smax = reinterpret_cast<uint32_t *>(sf + 8);
     // block -> (image, tile); blockIdx.y = N slice
@@ -251,7 +260,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
     const uint32_t wstep = (uint32_t)a.nslab * 2048u;
     auto dma_patch = [&](int it_) {                               // patch + depthwise parameters of loop step it_
         const int ks = kstep(it_);
-        unsigned char *HI = xsm + ((a.db & it_) & 1) * STG, *LO = HI + a.n16p * 16, *PARb = HI + a.n16p * 32;
+        unsigned char *HI = xsm + ((XB_DB & it_) & 1) * STG, *LO = HI + a.n16p * 16, *PARb = HI + a.n16p * 32;
         const bool gok = (ks * 4 + g4l) < G;
         const uint32_t koff = gok ? (uint32_t)ks * 128u : X_OOB;
 #pragma unroll
@@ -277,7 +286,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         const int wy0 = iy0 * st - a.st_pad_t, wx0 = ix0 * st - a.st_pad_l;
         float *win = reinterpret_cast<float *>(A);
         float inv = 1.f;
-        if (!a.in_f32) {
+        if (!F32IN) {
             unsigned mx = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) mx = max(mx, a.img_max[b * 32 + j]);
@@ -287,7 +296,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         // (a load inside a per-element branch makes the compiler drain the memory queue at every join).  u8 frames are fetched four
         // bytes per lane (unaligned dwords through a buffer descriptor: bytes before the first frame come back as zeros).
         const int rowf_ = WC * 3;
-        if (a.in_f32) {
+        if constexpr (F32IN) {
             constexpr int WQ = 16;                                    // window floats per thread: WR*WC*3 <= 16*TM*32 <= WQ*256
             const float *f = reinterpret_cast<const float *>(a.frames);
             const size_t fimg = (size_t)b * a.fH * a.fW * 3;
@@ -345,7 +354,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         XB_STAMP(12)
         // (2) one thread = one patch position, all st_cout channels
         unsigned char *HI = xsm, *LO = xsm + a.n16p * 16;
-        if (a.in_f32) xb_stem_patch<false, GL>(a, A, WC, 0, 1.f, iy0, ix0, HI, LO);
+        if constexpr (F32IN) xb_stem_patch<false, GL>(a, A, WC, 0, 1.f, iy0, ix0, HI, LO);
         else xb_stem_patch<true, GL>(a, A, WC, ((WC * 3 + 3) >> 2) * 4, inv, iy0, ix0, HI, LO);
     }
     XB_STAMP(1)
@@ -404,14 +413,14 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         }
         // two stages: the other one is free - request the patch of step ks+1 now (AFTER the weight loads: the memory counter retires in
         // order, and the weights are needed first)
-        if (a.db && ks + 1 < nk) dma_patch(ks + 1);
-        const unsigned char *HI = xsm + ((a.db & ks) & 1) * STG, *LO = HI + a.n16p * 16;
+        if (XB_DB && ks + 1 < nk) dma_patch(ks + 1);
+        const unsigned char *HI = xsm + ((XB_DB & ks) & 1) * STG, *LO = HI + a.n16p * 16;
         // the parameter slice is read as DWORDS, like the patch: a float-typed LDS read makes the compiler wait for every LDS-DMA in
         // flight (s_waitcnt vmcnt(0): the weight tile requested a moment ago) before it, a dword-typed one does not
         const unsigned char *PARB_ = HI + a.n16p * 32;
         const float up = sf[0], dmid = sf[1];
-        const bool f32patch = STEM || a.prepass || a.src_f32;
-        if (!STEM && a.prepass && !a.src_f32) {
+        const bool f32patch = STEM || XB_PREPASS || a.src_f32;
+        if (!STEM && XB_PREPASS && !a.src_f32) {
             // stride 1: a patch element feeds nine taps.  (hi, lo) -> fp32 once, in place (channels 0-3 over the hi plane's 16 bytes,
             // 4-7 over the lo plane's), instead of in every tap: 8 conversions per element here for 72 per item there
             for (int e = tid; e < a.n16p; e += 256) {
@@ -499,7 +508,7 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         asm volatile("" ::: "memory");
         if (ks == 0) { XB_STAMP(5) }
         if (ks == 1) { XB_STAMP(15) }
-        if (!a.db && ks + 1 < nk) dma_patch(ks + 1);
+        if (!XB_DB && ks + 1 < nk) dma_patch(ks + 1);
         // ---- pointwise: three products per tile (a wave whose 16*TN channels all lie past N - the last quarter of a 48- or 96-channel
         // layer in a 64- / 128-wide tile - has nothing to multiply nor, below, to stage)
         if (wave_live && !X_DBG(a, 16)) {
