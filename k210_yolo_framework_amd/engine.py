@@ -438,7 +438,8 @@ class Pipeline:
     library) let the GPU interleave workgroups of different batches; nothing is shared between them but the weight values.
 
     graph=True (default): a slot's step - (letterbox) -> yk_run_u8 -> decode + per-class NMS -> results - is captured once as a
-    hipGraph and REPLAYED: one host call per batch instead of ~30 launches (the host -> device copy of submit_host goes in front of it).  A captured step is bound to the
+    hipGraph and REPLAYED: one host call per batch instead of ~30 launches (the host -> device copy of submit_host runs in front of it on the
+    pipeline's copy stream, into one of the slot's two device input buffers, under the slot's previous batch).  A captured step is bound to the
     buffers it was captured with: device frames are replayed in place when they live at an address the slot has already captured
     (the slot's own `input(i)` buffer, or up to two caller buffers - a resident ring), and are copied into `input(i)` otherwise.
 
