@@ -595,6 +595,10 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         XB_STAMP(10)
         return;
     }
+    // (staged form) one descriptor per image for the output and for the residual: a pixel is a 32-bit offset inside its image
+    const uint32_t simg = (uint32_t)a.Ho * a.Wo * a.outG * 32u, rimg = (uint32_t)a.Ho * a.Wo * a.res.G * 32u;
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)b * simg), 0, simg, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res.p ? a.res.p + (size_t)b * rimg : a.out), 0, a.res.p ? rimg : 0u, 0x00020000);
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += IPP) {
         if (i0 > 0) __syncthreads();                                  // the previous pass has been copied out
@@ -605,9 +609,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
             const int py = (int)x_div((uint32_t)p, a.fd_tw), px = p - py * a.TW;
             const int oy = oy0 + py, ox = ox0 + px;
             const bool mok = py < a.TH && oy < a.Ho && ox < a.Wo;
-            const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+            const int m = oy * a.Wo + ox;                             // the pixel inside its image
             // the row's pixel index (or -1) rides in the 16 pad bytes of its staging row: the copy-out below needs no division per vector
-            if (wid == 0 && fq == 0) *reinterpret_cast<int *>(Cs + (p - i0 * 16) * C::CPITCH + BN * 4) = mok ? (int)m : -1;
+            if (wid == 0 && fq == 0) *reinterpret_cast<int *>(Cs + (p - i0 * 16) * C::CPITCH + BN * 4) = mok ? m : -1;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nl = (wid * TN + j) * 16 + nl4, n = n0 + nl;
@@ -617,8 +621,9 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
                 v[2] = x_actf(__builtin_fmaf(acc[i][j][2], scu[j].z, bs[j].z), a.slope, a.cap);
                 v[3] = x_actf(__builtin_fmaf(acc[i][j][3], scu[j].w, bs[j].w), a.slope, a.cap);
                 if (a.res.p && mok && (n >> 3) < a.res.G) {
-                    const uint8_t *q = a.res.p + (m * a.res.G + (n >> 3)) * 32 + (n & 7) * 2;
-                    const half4 rh = *reinterpret_cast<const half4 *>(q), rl = *reinterpret_cast<const half4 *>(q + 16);
+                    const uint32_t q = (uint32_t)((m * a.res.G + (n >> 3)) * 32 + (n & 7) * 2), q2 = q + 16u;
+                    const half4 rh = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsr, q, 0, 0));
+                    const half4 rl = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsr, q2, 0, 0));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * rup;
                 }
@@ -649,8 +654,8 @@ __global__ void __launch_bounds__(256, (TM * TN > 8 ? 2 : 4)) xb_kernel(const xb
         for (int v = tid; v < rows * VPR; v += 256) {
             const int pr = v / VPR, cv = v - pr * VPR;
             const int m = *reinterpret_cast<const int *>(Cs + pr * C::CPITCH + BN * 4), g = (n0 >> 3) + (cv >> 1);
-            if (m >= 0 && g < a.outG)
-                *reinterpret_cast<u32x4 *>(a.out + ((size_t)m * a.outG + g) * 32 + (cv & 1) * 16) = *reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16);
+            const uint32_t so = (m >= 0 && g < a.outG) ? (uint32_t)((m * a.outG + g) * 32 + (cv & 1) * 16) : X_OOB;   // (out of range: dropped by the descriptor)
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(Cs + pr * C::CPITCH + cv * 16), rss, so, 0, 0);
         }
     }
     XB_STAMP(9)
