@@ -792,6 +792,7 @@ void xdw_geometry(xdw_args &d, int max_batch) {
 #include "yk_xblock.h"
 #include "yk_xpersist.h"
 #include "yk_xheads.h"
+#include "yk_xfin.h"
 
 // =====================================================================================================================
 // stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once.
@@ -1004,7 +1005,7 @@ float x_h2f(uint16_t u) {
     return (float)h;
 }
 
-enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK, XK_PERSIST, XK_HEADS };
+enum { XK_STEM = 1, XK_CONV, XK_DW, XK_POOL, XK_ADD, XK_U8MAX, XK_BLOCK, XK_PERSIST, XK_HEADS, XK_FIN };
 enum { XT_REAL = 0, XT_UP = 1, XT_CAT = 2 };
 // tile configurations of xg_kernel
 enum { XC_64x64 = 0, XC_64x128, XC_128x64, XC_128x128, XC_NUM };
@@ -1039,6 +1040,8 @@ struct xlaunch {
     xp_args pa;                        // XK_PERSIST
     xh_args ha;                        // XK_HEADS
     unsigned h_lds = 0;
+    xf_args f;                         // XK_FIN: conv + BN + act -> 1x1 output conv in one launch (yk_xfin.h)
+    int fin_bm = 64, fin_bn = 0;
     int p_cw = 0;
     std::string name;
     double flops = 0, bytes = 0;
@@ -1098,6 +1101,30 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
     case XC_128x128: return x_launch_g_ns<128, 128, 2, 4>(g, std::min(ns, 3), st);
     }
     yk_set_error("f16x2: bad tile configuration %d", cfg);
+    return YK_ERR_ARG;
+}
+
+// a detection head in one launch (yk_xfin.h): grid = (BM-row tiles, 1, K slices)
+template <int BM, int BN>
+int x_launch_fin_bn(const xf_args &f, int ns, hipStream_t st) {
+    typedef xf_cfg<BM, BN> C;
+    const dim3 grid((unsigned)((f.c.M + BM - 1) / BM), 1u, (unsigned)f.c.splitk);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(3));
+        once = true;
+    }
+    if (ns >= 3) hipLaunchKernelGGL((xf_kernel<BM, BN, 3>), grid, dim3(C::NT), (unsigned)C::lds(3), st, f);
+    else hipLaunchKernelGGL((xf_kernel<BM, BN, 2>), grid, dim3(C::NT), (unsigned)C::lds(2), st, f);
+    return YK_OK;
+}
+int x_launch_fin(int bm, int bn, int ns, const xf_args &f, hipStream_t st) {
+    if (bm == 64 && bn == 128) return x_launch_fin_bn<64, 128>(f, ns, st);
+    if (bm == 64 && bn == 192) return x_launch_fin_bn<64, 192>(f, ns, st);
+    if (bm == 128 && bn == 128) return x_launch_fin_bn<128, 128>(f, ns, st);
+    if (bm == 128 && bn == 192) return x_launch_fin_bn<128, 192>(f, ns, st);
+    yk_set_error("f16x2: no fused head kernel for a %d x %d tile", bm, bn);
     return YK_ERR_ARG;
 }
 
@@ -1741,6 +1768,25 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             skip[i] = 1;
             gone[y] = 1;
         }
+    // A detection head: Conv2D (3x3 | 1x1, stride 1) + BN + act whose ONLY consumer is the next op, the 1x1 NET_OUTPUT conv (yolonet.py:27-29,
+    // 35-38): one launch (yk_xfin.h), the 128- / 192-channel tensor between them is never allocated.  Not where the heads cluster launch
+    // (latency schedule) collects these convs.  The rule looks at the network only, never at the batch.
+    std::vector<int> fin_of(n_ops, -1);
+    const bool heads_on = yk_env_flag("YK_HEADS", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOHEADS");
+    if (yk_env_flag("YK_FUSE_HEAD", true) && !heads_on)
+        for (int i = 0; i + 1 < n_ops; ++i) {
+            const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
+            const int y = o[YK_F_OUT], co = o[YK_F_COUT];
+            if (o[YK_F_TYPE] != YK_OP_CONV || skip[i] || dw_of[i] >= 0 || add_of[i] >= 0 || (o[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT) ||
+                p->T[o[YK_F_IN0]].is_input || o[YK_F_STRIDE] != 1 || (co != 128 && co != 192))
+                continue;
+            if (q[YK_F_TYPE] != YK_OP_CONV || !(q[YK_F_FLAGS] & YK_FLAG_NET_OUTPUT) || q[YK_F_K] != 1 || q[YK_F_STRIDE] != 1 || q[YK_F_IN0] != y ||
+                q[YK_F_COUT] > 80 || add_of[i + 1] >= 0 || p->T[y].uses != 1 || p->T[y].kind != XT_REAL)
+                continue;
+            fin_of[i] = i + 1;
+            skip[i + 1] = 1;
+            gone[y] = 1;
+        }
     for (int i = 1; i < n_tensors; ++i) {
         xtens &t = p->T[i];
         if (t.kind != XT_REAL || gone[i]) continue;
@@ -2054,7 +2100,38 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             // tile shape and K split are fixed here, for max_batch: an image's arithmetic never depends on the batch
             const long Mmax = (long)max_batch * Y.h * Y.w;
             const int nsteps = g.taps * (g.nc0 + g.nc1);
-            {
+            const bool fin = fin_of[i] >= 0;
+            if (fin) {
+                // one workgroup = 64 rows x all channels, at most six K slices, about 420 workgroups (the 64x64 split-K form: 735 / 1120 workgroups
+                // that each re-read their operands from L2)
+                // The slice count follows the IMAGE size (priced for the 32-image batch of the benchmark), never max_batch: an image's
+                // arithmetic must not depend on how many images the plan was built for.
+                int bm = 64;
+                if (const char *e = yk_dev_env("YK_XF_BM")) bm = atoi(e) == 128 ? 128 : 64;
+                const long tiles = (Mmax + bm - 1) / bm, tiles32 = (32L * Y.h * Y.w + bm - 1) / bm;
+                // measured with four batches in flight (tools/calls r6c5, developer build, one box; three-launch form 93.0 k images/s):
+                // slices (192-ch head, 128-ch head) = (8, 2) 94.0 k, (4, 4) 94.3 k, (6, 3) 94.8 k, (8, 4) 93.6 k; 128-row tiles 91.0 - 93.5 k
+                long sk = std::max<long>(1, std::min<long>(std::min<long>(6, (420 + tiles32 / 2) / tiles32), nsteps / 8));
+                if (!yk_env_flag("YK_SPLITK", true)) sk = 1;
+                if (const char *e = yk_dev_env("YK_XF_SPLITK")) sk = std::max(1, std::min(atoi(e), nsteps));
+                if (const char *e = yk_dev_env(co == 192 ? "YK_XF_SPLITK_192" : "YK_XF_SPLITK_128")) sk = std::max(1, std::min(atoi(e), nsteps));
+                g.splitk = (int)sk;
+                l.ns = 2;
+                if (const char *e = yk_dev_env("YK_XF_NS")) l.ns = std::max(2, std::min(3, atoi(e)));
+                l.fin_bm = bm;
+                l.fin_bn = co;
+                l.f.slab_bytes = 0;
+                if (g.splitk > 1) {
+                    void *sl;
+                    const size_t sb = (size_t)g.splitk * tiles * bm * co * 4;
+                    if ((rc = x_alloc(p, &sl, sb))) return fail(rc);
+                    g.slab = (float *)sl;
+                    l.f.slab_bytes = (uint32_t)sb;
+                }
+                void *tk;
+                if ((rc = x_alloc(p, &tk, (size_t)(tiles + 64) * 4))) return fail(rc);
+                l.f.ticket = (uint32_t *)tk;
+            } else {
                 int cfg;
                 if (co <= 64) cfg = Mmax >= 30000 ? XC_128x64 : XC_64x64;
                 else if (Mmax >= 60000 && co >= 96) cfg = XC_128x128;
@@ -2091,7 +2168,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                     g.slab = (float *)sl;
                 }
             }
-            const int BN = g_xc[l.cfg].bn;
+            const int BN = fin ? co : g_xc[l.cfg].bn;
             g.nslab = ((co + BN - 1) / BN) * (BN / 16);
             if ((rc = pack_w(o, c0, g.nc0, g.nc1, g.taps, g.nslab, &g.w, &g.w_bytes, &g.scale, &g.bias, &g.gain0, &g.gain1, &g.off))) return fail(rc);
             yk_act_params(o[YK_F_ACT], alpha, &g.slope, &g.cap);
@@ -2106,6 +2183,40 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 g.res = view_of(other);
                 dst_id = q[YK_F_OUT];
                 dst = &p->T[dst_id];
+            }
+            if (fin) {
+                // the conv's own output never exists; the launch ends in the 1x1 NET_OUTPUT conv
+                const int32_t *q = ops + (size_t)fin_of[i] * YK_OP_FIELDS;
+                xtens &Z = p->T[q[YK_F_OUT]];
+                xf_args &f = l.f;
+                f.N2 = q[YK_F_COUT];
+                f.nslab2 = 5;
+                uint32_t wb2;
+                float ga, gb, go, alpha2;
+                if ((rc = pack_w(q, co, co / 32, 0, 1, f.nslab2, &f.w2, &wb2, &f.scale2, &f.bias2, &ga, &gb, &go))) return fail(rc);
+                memcpy(&alpha2, &q[YK_F_ALPHA], 4);
+                yk_act_params(q[YK_F_ACT], alpha2, &f.slope2, &f.cap2);
+                f.out32 = Z.d32;
+                if (!f.out32) {
+                    yk_set_error("op %d: network output not allocated", fin_of[i]);
+                    return fail(YK_ERR_UNSUPPORTED);
+                }
+                if (S1 && (S0.cp % 32) != 0) {
+                    yk_set_error("op %d: f16x2 concat needs the first source's channels in multiples of 32 (got %d)", i, S0.cp);
+                    return fail(YK_ERR_UNSUPPORTED);
+                }
+                l.kind = XK_FIN;
+                l.Ho = Y.h;
+                l.Wo = Y.w;
+                f.c = g;
+                char tl[64];
+                snprintf(tl, sizeof tl, "[%dx%d,ring%d%s]", l.fin_bm, co, l.ns, g.splitk > 1 ? ",splitk" : "");
+                snprintf(nm, sizeof nm, "x:conv%dx%ds%d_%dto%d%s+conv1x1_%dto%d%s", ks, ks, g.stride, cin, co, S1 ? "+upcat" : (up0 ? "+up" : ""), co, f.N2, tl);
+                l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)cin * co + 2.0 * Y.h * Y.w * (double)co * f.N2;
+                l.bytes = ((double)S0.h * S0.w * c0 + (S1 ? (double)S1->h * S1->w * c1 : 0.0) + 2.0 * Y.h * Y.w * co + (double)Y.h * Y.w * f.N2) * 4;
+                l.name = nm;
+                p->L.push_back(l);
+                continue;
             }
             if (dst->net_out) {
                 g.out32 = dst->d32;
@@ -2283,6 +2394,13 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             g.M = batch * l.Ho * l.Wo;
             if (const char *e = yk_dev_env("YK_X_DBG")) g.dbg = atoi(e);
             int rc = x_launch_conv(l.cfg, l.ns, g, st);
+            if (rc) return rc;
+        } break;
+        case XK_FIN: {
+            xf_args f = l.f;
+            f.c.B = batch;
+            f.c.M = batch * l.Ho * l.Wo;
+            int rc = x_launch_fin(l.fin_bm, l.fin_bn, l.ns, f, st);
             if (rc) return rc;
         } break;
         case XK_BLOCK: {

@@ -16,10 +16,12 @@ def _outs(spec, w, frames, heads, max_batch=None):
     import torch
     from k210_yolo_framework_amd import engine
     os.environ['YK_HEADS'] = '1' if heads else '0'
+    os.environ['YK_FUSE_HEAD'] = '0'                                      # the reference form here is one launch per conv (tests/test_gpu_fin.py holds the fused heads)
     try:
         plan = engine.Plan(spec, w, max_batch=max_batch or len(frames), precision='f16x2')
     finally:
         os.environ.pop('YK_HEADS', None)
+        os.environ.pop('YK_FUSE_HEAD', None)
     names = [l[0] for l in plan.launches()]
     plan.run_u8(torch.from_numpy(frames).cuda())
     plan.check()
