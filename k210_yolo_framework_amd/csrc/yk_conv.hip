@@ -726,7 +726,9 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_lin_kernel(const igemm_arg
 }
 
 #include "yk_igemm_pipe.h"
-#include "yk_igemm_lc.h"
+#ifdef YK_DEV
+#include "yk_igemm_lc.h"                                           // loader / consumer waves: measured slower in the whole networks, developer builds only
+#endif
 
 int yk_launch_splitk_reduce(const igemm_args &a, bool out_f32, hipStream_t st) {
     const size_t total = (size_t)a.M * (a.ldn >> 2);
@@ -844,11 +846,15 @@ int yk_launch_igemm(int cfg, const igemm_args &a, hipStream_t st) {
         const int ns = ns_env ? ns_env : yk_big_ring_depth(cfg);
         if (cfg == IGEMM_256x128) return ns >= 3 ? launch_pipe<256, 128, 4, 2, 3>(a, st) : launch_pipe<256, 128, 4, 2, 2>(a, st);
         if (cfg == IGEMM_256x128W4) return ns >= 3 ? launch_pipe<256, 128, 2, 2, 3>(a, st) : launch_pipe<256, 128, 2, 2, 2>(a, st);
-        if (cfg >= IGEMM_LC_256x128) {                             // loader / consumer form (yk_igemm_lc.h): no upsampled source
+        if (cfg >= IGEMM_LC_256x128) {                             // loader / consumer form (yk_igemm_lc.h, developer builds): no upsampled source
+#ifdef YK_DEV
             if (a.up0) break;
             if (cfg == IGEMM_LC_256x128) return launch_lc<256, 128, 2, 2, 4, 3>(a, st);
             if (cfg == IGEMM_LC_128x256) return launch_lc<128, 256, 2, 2, 4, 3>(a, st);
             return ns >= 4 ? launch_lc<128, 128, 2, 2, 4, 4>(a, st) : launch_lc<128, 128, 2, 2, 4, 3>(a, st);
+#else
+            break;
+#endif
         }
         if (cfg == IGEMM_256x256) return launch_pipe<256, 256, 4, 2, 2>(a, st);
         if (cfg == IGEMM_128x256) return ns >= 3 ? launch_pipe<128, 256, 2, 2, 3>(a, st) : launch_pipe<128, 256, 2, 2, 2>(a, st);
@@ -899,8 +905,8 @@ int yk_igemm_pick(const igemm_args &a, bool out_f32) {
         // loader + consumer waves (yk_igemm_lc.h), 128x256 tile.  Alone, on a layer without residual and without split-K, it is ahead on the
         // long-K wide-N 3x3 layers (tools/r05_igemm_sweep.py, TFLOP/s at 32 / 64 images: 26x26 256->512 686 / 878 vs 658 / 745, 13x13 512->1024
         // 780 / 800 vs 665 / 708); picked for the whole of Darknet-53 it LOSES (6644 vs 7552 images/s at 32 images, 8328 vs 8708 at 64: its
-        // 128x256 tiles need split-K slabs + a finishing pass where the 64x128 tile fills the chip without) - off unless YK_IGEMM_LC=1
-        if (yk_env_flag("YK_IGEMM_LC", false) && dma_ok && ring_fits && !a.up0 && !a.in1 && a.N % 256 == 0 && a.K >= 1024 && a.M >= 4096) return IGEMM_LC_128x256;
+        // 128x256 tiles need split-K slabs + a finishing pass where the 64x128 tile fills the chip without) - developer builds only, YK_IGEMM_LC=1
+        if (yk_dev_env("YK_IGEMM_LC") && yk_dev_env("YK_IGEMM_LC")[0] == '1' && dma_ok && ring_fits && !a.up0 && !a.in1 && a.N % 256 == 0 && a.K >= 1024 && a.M >= 4096) return IGEMM_LC_128x256;
         if (dma_ok && ring_fits && !a.up0 && a.N % 128 == 0 && a.M >= 150000 && a.K >= 256) return IGEMM_128x128R;
     }
     if (a.K >= 512) return (a.N % 128 == 0 && dma_ok) ? IGEMM_64x128 : IGEMM_64x64;

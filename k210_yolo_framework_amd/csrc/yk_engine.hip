@@ -393,7 +393,7 @@ extern "C" int yk_plan_create_ex(yk_plan_t **out, const int32_t *ops, int n_ops,
             g.w = (const yk_half *)dwt;
             g.w_bytes = (uint32_t)(w.size() * 2);
             g.wfrag = nullptr; g.wfrag_bytes = 0; g.nb16 = (co + 15) / 16;
-            if (g.K % 64 == 0 && yk_env_flag("YK_PIPE_BR", false)) {     // fragment-order copy for yk_igemm_br.h (experiment switch)
+            if (g.K % 64 == 0 && yk_dev_env("YK_PIPE_BR") && yk_dev_env("YK_PIPE_BR")[0] == '1') {     // fragment-order copy for yk_igemm_br.h (developer builds)
                 const int nb = g.nb16, nsteps = g.K / 64;
                 std::vector<uint16_t> wf((size_t)nsteps * nb * 1024, 0);
                 for (int st = 0; st < nsteps; ++st)

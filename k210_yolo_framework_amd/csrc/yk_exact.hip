@@ -49,8 +49,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
 
-// activation min(max(v, v * slope), cap) as ONE median: for slope in [0, 1] and cap >= 0 the three values are ordered (v * slope, v, cap)
-// or (v, v * slope, cap) - or cap sits below v - and the median is the clamped value (leaky / linear layers have cap = +inf, ReLU6 slope 0)
+// activation min(max(v, v * slope), cap) as ONE median.  Valid for the combinations the reference networks use - leaky / linear layers
+// (slope in (0, 1], cap = +inf: median(v, v*slope, inf) = max) and ReLU / ReLU6 (slope 0, cap >= 0: median(v, 0, cap) = clamp) - NOT for a
+// capped leaky activation (v = 20, slope 0.5, cap 6: the median is 10): yk_xplan_create refuses that combination
 __device__ __forceinline__ float x_actf(float v, float slope, float cap) { return __builtin_amdgcn_fmed3f(v, v * slope, cap); }
 __device__ __forceinline__ uint32_t x_div(uint32_t n, yk_fastdiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
 
@@ -1048,14 +1049,13 @@ struct xlaunch {
 };
 
 // interleaved DMA issue (IL): measured no faster (K2 step 646.6 vs 637.4 us of kernels, Darknet-53 f16x2 3119 vs 3089 images/s; gpurun_out/r5c3):
-// a wave blocks on the vector-memory issue of a piece wherever the piece sits in its stream - off unless YK_X_IL=1
+// a wave blocks on the vector-memory issue of a piece wherever the piece sits in its stream - developer builds only (YK_X_IL=1)
 static bool x_interleave() {
 #ifdef YK_DEV
     const char *e = getenv("YK_X_IL");
     return e && e[0] == '1';
 #else
-    static const bool on = yk_env_flag("YK_X_IL", false);
-    return on;
+    return false;
 #endif
 }
 template <int BM, int BN, int WM, int WN, int NS>
@@ -1066,24 +1066,35 @@ int x_launch_g(const xg_args &g, hipStream_t st) {
     auto allow = [&](const void *k, unsigned bytes) {
         if (bytes > 64 * 1024) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     };
-    const bool il = x_interleave();
     static bool once = false;
     if (!once) {
         allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true, false>), lds);
-        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true, true>), lds);
         allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false, false>), lds);
-        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false, true>), lds);
         allow(reinterpret_cast<const void *>(xg_reduce_kernel<BM, BN, WM, WN>), rlds);
+#ifdef YK_DEV
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, true, true>), lds);
+        allow(reinterpret_cast<const void *>(xg_kernel<BM, BN, WM, WN, NS, false, true>), lds);
+#endif
         once = true;
     }
+#ifdef YK_DEV
+    if (x_interleave()) {
+        if (g.splitk > 1) {
+            hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, true>), grid, dim3(C::NT), lds, st, g);
+            grid.z = 1;
+            hipLaunchKernelGGL((xg_reduce_kernel<BM, BN, WM, WN>), grid, dim3(C::NT), rlds, st, g);
+        } else {
+            hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, true>), grid, dim3(C::NT), lds, st, g);
+        }
+        return YK_OK;
+    }
+#endif
     if (g.splitk > 1) {
-        if (il) hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, true>), grid, dim3(C::NT), lds, st, g);
-        else hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, false>), grid, dim3(C::NT), lds, st, g);
+        hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, true, false>), grid, dim3(C::NT), lds, st, g);
         grid.z = 1;
         hipLaunchKernelGGL((xg_reduce_kernel<BM, BN, WM, WN>), grid, dim3(C::NT), rlds, st, g);
     } else {
-        if (il) hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, true>), grid, dim3(C::NT), lds, st, g);
-        else hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, false>), grid, dim3(C::NT), lds, st, g);
+        hipLaunchKernelGGL((xg_kernel<BM, BN, WM, WN, NS, false, false>), grid, dim3(C::NT), lds, st, g);
     }
     return YK_OK;
 }
@@ -1773,7 +1784,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
     // (latency schedule) collects these convs.  The rule looks at the network only, never at the batch.
     std::vector<int> fin_of(n_ops, -1);
     const bool heads_on = yk_env_flag("YK_HEADS", latency_schedule != 0) && fuse_blocks && !yk_dev_env("YK_X_NOHEADS");
-    if (yk_env_flag("YK_FUSE_HEAD", true) && !heads_on)
+    if (yk_env_flag("YK_FUSE_HEAD", true) && fuse_blocks && !heads_on)                  // (YK_FUSE_DWPW=0: one launch per layer, everywhere)
         for (int i = 0; i + 1 < n_ops; ++i) {
             const int32_t *o = ops + (size_t)i * YK_OP_FIELDS, *q = o + YK_OP_FIELDS;
             const int y = o[YK_F_OUT], co = o[YK_F_COUT];
@@ -2307,6 +2318,15 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
         l.name = nm;
         p->L.push_back(l);
+    }
+    for (const xlaunch &l : p->L) {                                 // x_actf's one-median form (top of this file) does not cover a capped leaky activation
+        auto bad = [](float slope, float cap) { return slope > 0.f && std::isfinite(cap); };
+        if ((l.kind == XK_CONV && bad(l.c.slope, l.c.cap)) || (l.kind == XK_DW && bad(l.d.slope, l.d.cap)) || (l.kind == XK_STEM && bad(l.s.slope, l.s.cap)) ||
+            (l.kind == XK_BLOCK && (bad(l.b.slope, l.b.cap) || bad(l.b.dw_slope, l.b.dw_cap) || (l.b.stem && bad(l.b.st_slope, l.b.st_cap)))) ||
+            (l.kind == XK_FIN && (bad(l.f.c.slope, l.f.c.cap) || bad(l.f.slope2, l.f.cap2)))) {
+            yk_set_error("f16x2: %s has a leaky activation with a finite cap (not a reference layer)", l.name.c_str());
+            return fail(YK_ERR_UNSUPPORTED);
+        }
     }
     // A tensor whose ONLY reader is a depthwise conv (of a fused block, a plain depthwise launch or the persistent stage's first phase) is
     // stored as fp32 planes - the same 32 bytes per channel group as (hi | lo): its producer (fused block or conv launch without a residual)

@@ -22,10 +22,7 @@
 // two waves share a fragment.  OFF unless YK_PIPE_BR=1 (the plan then also builds the fragment-order copy).
 #pragma once
 
-template <int N>
-__device__ __forceinline__ void yk_wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
+
 
 template <int BM, int BN, int WM, int WN, int NS, int OUT>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_br_kernel(const igemm_args a) {

@@ -20,7 +20,17 @@
 // the row keeps (y0, x0) instead of a precomputed pointer.
 #pragma once
 
-#include "yk_igemm_br.h"                                           // (the variant with the weight fragments in registers; defines yk_wait_vm_lgkm0)
+#include <mutex>
+#include <set>
+#include <utility>
+
+template <int N>
+__device__ __forceinline__ void yk_wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+#ifdef YK_DEV
+#include "yk_igemm_br.h"                                           // (developer builds: the variant with the weight fragments in registers)
+#endif
 
 // IL (round 5): the DMA pieces of the step being prefetched are issued BETWEEN the MFMAs of the step being computed, one piece per few MFMAs
 // (an LDS-DMA instruction costs its wave ~150 cycles of issue when a whole step's pieces go out in one block ahead of the fragment reads,
@@ -301,51 +311,52 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_pipe_kernel(const igemm_ar
 #undef PIPE_CLK0
 }
 
-// software-pipelined loop (IL): measured no faster than the plain loop (gpurun_out/r5c5: 7001 vs 7285 images/s on Darknet-53) - off unless YK_PIPE_IL=1
-static bool yk_pipe_interleave() {
+// The round-5 loop forms (IL: DMA pieces between the MFMAs; PS: phase-split waves; BR: weight fragments in registers, yk_igemm_br.h) were all
+// measured equal or slower in the whole networks ("measured and rejected"): they exist in developer builds only (-DYK_DEV).
 #ifdef YK_DEV
+static bool yk_pipe_interleave() {
     const char *e = getenv("YK_PIPE_IL");
     return e && e[0] == '1';
-#else
-    static const bool on = yk_env_flag("YK_PIPE_IL", false);
-    return on;
-#endif
 }
-
-// phase split (PS): off unless YK_PIPE_PS=1
 static int yk_pipe_phase_split() {
-#ifdef YK_DEV
     const char *e = getenv("YK_PIPE_PS");
     return (e && e[0] != '0') ? 1 : 0;
-#else
-    static const int on = yk_env_flag("YK_PIPE_PS", false) ? 1 : 0;
-    return on;
+}
 #endif
+
+// more than 64 KB of dynamic LDS needs the attribute on EVERY kernel (instantiation) that is launched with it, on every device
+static inline void yk_allow_lds(const void *kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({dev, kern}).second) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
 static int launch_pipe(const igemm_args &a, hipStream_t st) {
+#ifdef YK_DEV
     if constexpr (NS == 2 && BM * BN <= 128 * 128)
         if (!a.up0 && a.wfrag && yk_pipe_br()) return launch_br<BM, BN, WM, WN, NS>(a, st);     // weight fragments in registers (yk_igemm_br.h)
+#endif
     constexpr size_t ring = (size_t)NS * (BM + BN) * 64 * 2, ct = (size_t)BM * (BN + 8) * 2;
     constexpr size_t ldsd = ring > ct ? ring : ct;
     dim3 g2((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
     auto go = [&](auto kern) {
-        if (ldsd > 64 * 1024) {
-            static bool done = false;
-            if (!done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd);
-                done = true;
-            }
-        }
+        yk_allow_lds(reinterpret_cast<const void *>(kern), ldsd);
         hipLaunchKernelGGL(kern, g2, dim3(64 * WM * WN), ldsd, st, a);
     };
-    const bool il = yk_pipe_interleave();
-    const int ps = NS >= 3 ? yk_pipe_phase_split() : 0;
     if (a.up0) {
         if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, true>);
         else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, true>);
-    } else if (ps && NS >= 3) {
+        return YK_OK;
+    }
+#ifdef YK_DEV
+    const bool il = yk_pipe_interleave();
+    const int ps = NS >= 3 ? yk_pipe_phase_split() : 0;
+    if (ps && NS >= 3) {
         if constexpr (NS >= 3) {
             if (WM * WN >= 8) {
                 if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false, false, 1>);
@@ -355,12 +366,15 @@ static int launch_pipe(const igemm_args &a, hipStream_t st) {
                 else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false, false, 2>);
             }
         }
-    } else if (il) {
+        return YK_OK;
+    }
+    if (il) {
         if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false, true>);
         else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false, true>);
-    } else {
-        if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false>);
-        else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false>);
+        return YK_OK;
     }
+#endif
+    if (a.split_k > 1) go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 2, false>);
+    else go(igemm_pipe_kernel<BM, BN, WM, WN, NS, 0, false>);
     return YK_OK;
 }

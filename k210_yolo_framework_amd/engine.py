@@ -500,6 +500,7 @@ class Pipeline:
             self.slots.append(s)
         self._n = 0
         self.host_us = 0.0
+        self.host_wait_us = 0.0                                                         # submit_host: time the submit thread spent BLOCKED on a slot's input buffer (cumulative)
         self._copy_stream = None                                                        # submit_host: the H2D leg's own stream (created on first use)
 
     # -- buffers ------------------------------------------------------------------------------------
@@ -552,11 +553,14 @@ class Pipeline:
         b = s.h2d_next
         s.h2d_next ^= 1
         dst, cs = s.h2d_bufs[b], self._copy_stream
-        if s.h2d_free[b] is not None:
+        if s.h2d_free[b] is not None and not s.h2d_free[b].query():
             # the batch that last read this buffer (two submits of this slot ago) - waited for on the HOST, where it is over long ago in steady
             # state: a wait inside the copy stream would put barrier packets into a fifth hardware queue, and a fifth active queue costs the
             # four compute streams a quarter of their rate (the part has four compute pipes; measured 85 -> 61 k images/s)
+            import time
+            t0 = time.perf_counter()
             s.h2d_free[b].synchronize()
+            self.host_wait_us += (time.perf_counter() - t0) * 1e6      # blocked, not busy: bench.py reports the two apart
         _check(lib().yk_memcpy_async(C.c_void_p(dst.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()),
                                      C.c_void_p(cs.cuda_stream)), 'yk_memcpy_async')
         s.h2d_copied[b].record(cs)

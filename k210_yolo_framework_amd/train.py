@@ -334,7 +334,7 @@ class Trainer:
             dy = D.pop(op['out'], None)
             if dy is None:
                 continue
-            x = self.T[op['in0']]
+            x = self.T.get(op['in0'])                               # (None for an Add whose conv input was folded into the producer: never stored, never read here)
             ho, wo, co = self.spec.tensors[op['out']]
             hi, wi, ci = self.spec.tensors[op['in0']]
             M = self.B * ho * wo
@@ -416,7 +416,12 @@ class Trainer:
                 pf = max(pa, pb)
                 others = [j for j, q in enumerate(self.spec.ops) if j != i and (q.get('in0') == second or q.get('in1') == second)]
                 lone = not [j for j, q in enumerate(self.spec.ops) if j != i and (q.get('in0') == first or q.get('in1') == first)] and first not in self.spec.outputs
-                share = a_ != b_ and lone and first not in D and second not in D and all(j < pf for j in others) and second != 0
+                # ... and `first`'s producer must be a conv WITH BatchNorm: its backward only READS dy and writes a fresh dz.  Another Add would store
+                # dy again by reference, a conv without BN hands dy on as dz (and, with a weight-gradient stream, reads it later) - then a later
+                # accumulation into D[second] would corrupt a buffer somebody else still holds: clone.
+                pq = self.spec.ops[pf] if pf >= 0 else None
+                fresh = pq is not None and pq['type'] in (ns.OP_CONV, ns.OP_DWCONV) and bool(self.lay[pq['layer']].bn_name)
+                share = a_ != b_ and lone and fresh and first not in D and second not in D and all(j < pf for j in others) and second != 0
                 acc(second, dy, share)
                 acc(first, dy, True)
         flush()

@@ -50,3 +50,16 @@ def test_a_rank_count_that_contradicts_the_launcher_is_refused():
     r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '4', '--stub'], capture_output=True, text=True, timeout=120,
                        cwd=str(ROOT), env=env)
     assert r.returncode != 0 and 'the launcher started 2 ranks' in (r.stderr + r.stdout)
+
+
+def test_gpus_8_stub_eight_ranks_report_every_rank_and_the_slowest_defines_the_time():
+    """SURVEY 8(e) / BASELINE "1/2/4/8-GPU scaling": the 8-rank launch path (rendezvous on 127.0.0.1, image i -> rank i mod 8, barrier,
+    max over ranks, per-rank rates in the line) exercised without an 8-GPU node."""
+    out = _line(_run('--gpus', '8', '--stub', '--steps', '10', '--warmup', '1', timeout=400))
+    assert out['n_gpus'] == 8 and out['config']['global_batch'] == 256 and out['config']['images_of_rank0'] == 32
+    pr = out['from_host_per_rank']
+    assert len(pr['images_per_sec']) == 8 and pr['min'] == min(pr['images_per_sec']) and pr['max'] == max(pr['images_per_sec'])
+    # rank r sleeps 2 ms * (1 + r / 2) per step: rank 7 (9 ms) is the slowest and defines the whole-job time
+    assert pr['images_per_sec'][7] == pr['min'] and pr['images_per_sec'][0] == pr['max']
+    assert out['ms_per_step'] >= 9.0
+    assert abs(out['value'] - 256 / (out['ms_per_step'] * 1e-3)) / out['value'] < 0.01

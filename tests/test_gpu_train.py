@@ -286,6 +286,70 @@ def test_training_step_loss_and_all_gradients_vs_autograd(name, hw, B, alpha):
     assert compared >= 1, 'no flip-free seed found'
 
 
+def _residual_zoo_spec():
+    """Residual wiring the reference networks do NOT use (NetSpec is a general builder): Add(conv_out, shortcut) with the operands swapped,
+    an Add whose input is another Add's output, a shortcut read by three consumers, and a linear (no-BN) conv feeding an Add."""
+    s = ns.NetSpec('zoo', (32, 48), anchor_num=3, class_num=20)
+    x = s._new_tensor(32, 48, 3)
+    x = s.conv(x, 16, 3, 2, ns.K210_S2_PAD, act=ns.LEAKY03, name='conv1')
+    a = s.conv(x, 16, 1, act=ns.RELU6, name='conv_a')
+    r1 = s.add(a, x)                                       # operands swapped: (conv output, shortcut)
+    b = s.conv(r1, 16, 1, act=ns.LEAKY03, name='conv_b')
+    r2 = s.add(r1, b)                                      # the usual order
+    r3 = s.add(r2, r1)                                     # nested: r2 is itself an Add; r1 now has three readers
+    c = s.conv(r3, 16, 1, bn=False, bias=True, name='conv_c')   # no BatchNorm: its backward hands dy on as dz
+    r4 = s.add(r3, c)
+    x1 = s.conv(r4, 16, 1, act=ns.LEAKY03, name='conv_pw_1')
+    t = s.dwconv(x1, 2, ns.K210_S2_PAD, act=ns.RELU, name='conv_dw_2')
+    x2 = s.conv(t, 32, 1, act=ns.LEAKY03, name='conv_pw_2')
+    ns._head(s, x1, x2, 24, 16, 8, 75, [0])
+    return s
+
+
+@pytest.mark.parametrize('wstream', [0, 2])
+def test_nested_and_swapped_adds_gradients_vs_autograd(wstream, monkeypatch):
+    """the Add backward may share dy between its two inputs only when the later producer is a BatchNorm conv (a fresh dz); and a
+    folded Add must work whichever operand is the conv's output.  Gradients of every parameter against float64 autograd, with and without
+    the weight-gradient side stream."""
+    from k210_yolo_framework_amd.train import Trainer
+    monkeypatch.setenv('YK_TRAIN_WSTREAM', str(wstream))
+    hyper = dict(obj_thresh=0.7, iou_thresh=0.5, obj_weight=1.0, noobj_weight=1.0, wh_weight=1.0)
+    spec = _residual_zoo_spec()
+    h = Helper(None, 20, VOC_ANCHORS, [[32, 48]], [list(v) for v in spec.out_hw()])
+    compared = 0
+    for seed in range(3, 15):
+        w = spec.init_weights(seed)
+        rng = np.random.default_rng(seed)
+        B = 4
+        ys = [[] for _ in spec.outputs]
+        for _ in range(B):
+            n = int(rng.integers(1, 4))
+            boxes = np.stack([rng.integers(0, 20, n), rng.uniform(.2, .8, n), rng.uniform(.2, .8, n), rng.uniform(.1, .6, n), rng.uniform(.1, .6, n)], 1)
+            for i, lab in enumerate(h.box_to_label(boxes)):
+                ys[i].append(lab)
+        yt = [np.stack(y).astype(np.float32) for y in ys]
+        x = rng.uniform(0, 1, (B, 32, 48, 3)).astype(np.float32)
+        ref_data, ref_reg, ref_g, ref_stats, _ = train_ref.loss_and_grads(spec, w, x, yt, h.anchors, want_pre=True, **hyper)
+        tr = Trainer(spec, w, h.anchors, B, lr=5e-4, decay=0.0, **hyper)
+        r = tr.loss_and_grads(_cu(x), [_cu(y) for y in yt])
+        torch.cuda.synchronize()
+        data = float(sum(p[0] for p in r['layers']).cpu())
+        assert abs(data - ref_data) <= 1e-4 * abs(ref_data), (data, ref_data)
+        if _gate_flips(tr, spec, ref_stats):
+            continue
+        got = tr.grads()
+        gmax = max(np.abs(v).max() for v in ref_g.values())
+        for k, rg in ref_g.items():
+            if np.abs(rg).max() < 1e-9 * gmax:
+                assert np.abs(got[k]).max() <= 1e-6 * gmax, k
+                continue
+            assert np.abs(got[k] - rg).max() / np.abs(rg).max() <= 2e-3, (k, seed)
+        compared += 1
+        if compared == 2:
+            break
+    assert compared >= 1, 'no flip-free seed found'
+
+
 def test_adam_step_moves_weights_like_reference_and_loss_decreases():
     from k210_yolo_framework_amd.train import Trainer
     spec, w, h, x, yt = _case('yolo_mobilev1', (64, 96), 4, 0.5, 9)

@@ -94,3 +94,34 @@ def test_numa_binding_reads_sysfs_and_binds_to_the_gpus_node(tmp_path):
     assert shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:c1:00.0')['cpus'] is None
     assert shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:ff:00.0')['node'] == -1
     assert os.sched_getaffinity(0) == before
+
+
+def test_bind_to_gpu_numa_on_a_faked_sysfs_tree_eight_devices_over_two_nodes(tmp_path):
+    """eight ranks, GPUs 0-3 on node 0 and 4-7 on node 1 - each rank must pick the CPUs of ITS GPU's node (no 8-GPU box here:
+    the sysfs tree is faked; apply=False so the test process keeps its own affinity)."""
+    import os
+    from k210_yolo_framework_amd import shard
+    ncpu = max(os.sched_getaffinity(0)) + 1
+    half = max(1, ncpu // 2)
+    lists = {0: f'0-{half - 1}', 1: f'{half}-{max(half, ncpu - 1)}'}
+    for node, cl in lists.items():
+        d = tmp_path / 'devices' / 'system' / 'node' / f'node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cl + '\n')
+    pcis = [f'0000:{0x10 + 0x10 * g:02x}:00.0' for g in range(8)]
+    for g, pci in enumerate(pcis):
+        d = tmp_path / 'bus' / 'pci' / 'devices' / pci
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{g // 4}\n')
+    allowed = set(os.sched_getaffinity(0))
+    for g, pci in enumerate(pcis):
+        info = shard.bind_to_gpu_numa(g, sysfs=str(tmp_path), pci_bus_id=pci.upper(), apply=False)
+        want = set(shard.parse_cpulist(lists[g // 4])) & allowed
+        assert info['pci'] == pci.upper() and info['node'] == g // 4
+        assert info['cpus'] == (len(want) if want else None)
+    assert os.sched_getaffinity(0) == allowed                             # apply=False changed nothing
+    # a device sysfs does not know (container without the PCI tree) and a node whose CPUs the cpuset excludes: nothing to bind, reported as such
+    assert shard.bind_to_gpu_numa(0, sysfs=str(tmp_path), pci_bus_id='0000:ff:00.0', apply=False) == {'pci': '0000:ff:00.0', 'node': -1, 'cpus': None}
+    d = tmp_path / 'devices' / 'system' / 'node' / 'node1' / 'cpulist'
+    d.write_text(f'{ncpu + 64}-{ncpu + 71}\n')
+    assert shard.bind_to_gpu_numa(5, sysfs=str(tmp_path), pci_bus_id=pcis[5], apply=False)['cpus'] is None

@@ -23,5 +23,5 @@ torch.cuda.synchronize()
 names = [l[0] for l in plan.launches()] + ['decode_py', 'nms_py', 'compact_py']
 os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
 json.dump({'launches': names, 'alg_bytes_per_image': [l[2] for l in plan.launches()], 'steps': steps, 'precision': precision, 'schedule': schedule,
-           'kernels_per_launch': [2 if 'splitk' in n else 1 for n in names]},
+           'kernels_per_launch': [2 if ('splitk' in n and not (n.startswith('x:conv') and '+conv1x1_' in n)) else 1 for n in names]},   # (a fused head is ONE kernel)
           open(os.path.join(root, 'gpurun_out', f'launch_names_{schedule}.json'), 'w'))
