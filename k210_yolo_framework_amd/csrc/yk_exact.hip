@@ -794,6 +794,9 @@ void xdw_geometry(xdw_args &d, int max_batch) {
 #include "yk_xpersist.h"
 #include "yk_xheads.h"
 #include "yk_xfin.h"
+#ifdef YK_DEV
+#include "yk_xwblock.h"                                            // two-role fused block: faster alone, slower with four batches in flight - developer builds
+#endif
 
 // =====================================================================================================================
 // stem conv (Cin = 3), fp32 VALU; u8 frames are normalised as float(v)/float(max) = numpy's `img / np.max(img)` rounded once.
@@ -1033,6 +1036,7 @@ struct xlaunch {
     xadd_args ad;
     xb_args b;
     int tm = 0, tn = 0;                // xb_kernel<tm, tn>
+    int ws = 0;                        // ... as xw_kernel<tm, tn> (wave-specialised, yk_xwblock.h)
     int Ho = 0, Wo = 0;
     int cfg = 0, ns = 2;               // xg_kernel tile configuration and ring depth
     unsigned lds = 0;
@@ -1173,7 +1177,28 @@ bool xb_has(int tm, int tn) {
     for (int v : g_xb_tn) b |= v == tn;
     return a && b;
 }
-int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hipStream_t st) {
+#ifdef YK_DEV
+// the wave-specialised form (yk_xwblock.h): producers run the depthwise pass of step k while consumers multiply step k-1
+template <int TM, int TN>
+int x_launch_w(const xb_args &g, int batch, hipStream_t st) {
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xw_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    dim3 grid((unsigned)(batch * g.tiles_x * g.tiles_y), (unsigned)((g.N + 64 * TN - 1) / (64 * TN)));
+    hipLaunchKernelGGL((xw_kernel<TM, TN>), grid, dim3(512), (unsigned)g.lds_bytes, st, g);
+    return YK_OK;
+}
+#endif
+int x_launch_block(int tm, int tn, const xb_args &g, int batch, unsigned lds, hipStream_t st, int ws = 0) {
+#ifdef YK_DEV
+    if (ws && tm == 4 && tn == 6) return x_launch_w<4, 6>(g, batch, st);
+    if (ws && tm == 4 && tn == 3) return x_launch_w<4, 3>(g, batch, st);
+    if (ws && tm == 2 && tn == 3) return x_launch_w<2, 3>(g, batch, st);
+#else
+    (void)ws;
+#endif
 #define XB_CASE(M, N) \
     if (tm == M && tn == N) return x_launch_b<M, N>(g, batch, lds, st);
     XB_CASE(2, 1) XB_CASE(2, 2) XB_CASE(2, 3) XB_CASE(2, 6)
@@ -2360,6 +2385,26 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
             if (cons->kind == XK_BLOCK) cons->b.src_f32 = 1; else cons->d.in_f32 = 1;
             T.f32 = true;
         }
+    // Developer builds, YK_XB_WS=1: the long-walk blocks (12 channel steps to 384 outputs: the five 14x20x384 blocks of yolo_mobilev1-0.75) run
+    // wave-specialised (yk_xwblock.h): depthwise pass of step k on four waves while four others multiply step k-1.  Bit-identical outputs;
+    // measured (tools/calls r6c9, one box): the launch alone 36.5 -> 29.1 us (sum of kernels 598 -> 561 us), but `value` 99.1 -> 95.8 k images/s:
+    // its eight waves x 217 registers take the whole CU, where the one-role kernel leaves half of it to the other batches' workgroups.
+    if (yk_dev_env("YK_XB_WS") && yk_dev_env("YK_XB_WS")[0] == '1')
+        for (xlaunch &l : p->L) {
+            if (l.kind != XK_BLOCK || l.b.stem || l.b.GL != 4) continue;
+            const bool pick = (l.tm == 4 && l.tn == 6) || (yk_dev_env("YK_XB_WS_ALL") && ((l.tm == 4 && l.tn == 3) || (l.tm == 2 && l.tn == 3)));
+            if (!pick) continue;
+            const int bm = 16 * l.tm, bn = 64 * l.tn, ipp = (l.tn >= 3 && l.tm >= 2) ? (l.tm + 1) / 2 : l.tm;
+            const bool staged = !(l.b.dst_f32 && !l.b.res.p);
+            const int ring = 2 * (l.b.n16p * 32 + 2048) + 2 * bm * 128, ct = staged ? ipp * 16 * (bn * 4 + 16) : 0;
+            const int lds = std::max(ring, ct) + 64;
+            if (lds > 160 * 1024) continue;
+            l.ws = 1;
+            l.lds = (unsigned)lds;
+            l.b.lds_bytes = lds;
+            const size_t at = l.name.rfind(']');
+            if (at != std::string::npos) l.name.insert(at, ",2roles");
+        }
     // The two cluster launches hold every CU for their whole duration: the shortest time of ONE batch (one-batch latency 669 -> 542 us of
     // kernels), but with several batches in flight on several streams the launch-per-layer form overlaps better (78 k vs 68 k images/s, four in
     // flight; profiles/r04_schedules.txt).  YK_SCHEDULE_LATENCY selects them; YK_PERSIST / YK_HEADS = 0|1 override either way.
@@ -2433,7 +2478,7 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             }
             if (const char *e = yk_dev_env("YK_XB_DBG")) g.dbg = atoi(e);
             g.stamps = (li == p->dbg_launch) ? p->d_dbg : nullptr;
-            int rc = x_launch_block(l.tm, l.tn, g, batch, l.lds, st);
+            int rc = x_launch_block(l.tm, l.tn, g, batch, l.lds, st, l.ws);
             if (rc) return rc;
         } break;
         case XK_DW: {
