@@ -215,57 +215,109 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             },
             [](int) {});
     } else {
-        // More candidates than the LDS holds (degenerate inputs: saturated logits).  Greedy NMS only ever needs the candidates
-        // in descending (score, -index) order, and a candidate's fate depends only on the boxes selected before it - so the
-        // list is processed in CHUNKS of at most MAXC consecutive keys: find a key interval [lo, hi) holding <= MAXC
-        // candidates by bisection on the 64-bit key (score bits, ~index) with counting passes over the score plane, gather it
-        // into LDS, drop what the boxes selected so far suppress, run the LDS greedy on the rest, continue below lo.
-        // Exact, and ~12 coalesced passes per chunk instead of two passes per selected box (the old in-place loop: 10 ms on
-        // 10 647 boxes x 20 classes x 16 images).
+        // More candidates than the LDS holds (degenerate inputs: saturated logits - what 75 undamped random-init Darknet layers produce).  Greedy
+        // NMS only ever needs the candidates in descending (score, -index) order, and a candidate's fate depends only on the boxes selected
+        // before it - so the list is processed in CHUNKS of at most MAXC consecutive keys: find a key `lo` with count([lo, hi)) <= MAXC, gather
+        // that interval into LDS, drop what the boxes selected so far suppress, run the LDS greedy on the rest, continue below lo.
+        // `lo` comes from an MSD RADIX SELECT on the 64-bit key (score bits, ~index): one histogram pass (2^NBL bins in LDS) per level, the
+        // bin that crosses MAXC is split by the next level - 1-2 passes for distinct scores, <= 5 when thousands of scores tie (then the
+        // index bits decide).  Round 5 bisected on the key with one counting pass per step: ~45 passes per chunk, 1.44 ms of a 5.7 ms
+        // Darknet-53 step at 32 images (profiles/r06_darknet_pipeline_kernel_stats.csv); the old in-place loop before that: 10 ms.
+        constexpr int NBL = MAXC >= 2048 ? 11 : 10, NB = 1 << NBL;
         const unsigned long long key_min = (unsigned long long)__float_as_uint(fmaxf(obj_thresh, 0.f)) << 32;
         auto key_of = [&](float v, int i) { return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~i); };
-        auto count_in = [&](unsigned long long lo, unsigned long long hi) {
-            int cl = 0;
-            for (int i0 = 0; i0 < ntot; i0 += 64 * 4) {
-                float v[4];
+        int *hist = L.idx;                                        // free between chunks (the selected indices live in selg / og)
+        // histogram of the keys in [lo_c, hi_c) over bins of 2^sh keys
+        auto hist_pass = [&](unsigned long long lo_c, unsigned long long hi_c, int sh) {
+            for (int q = lane; q < NB; q += 64) hist[q] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < ntot; i0 += 64 * 16) {          // sixteen independent loads in flight per lane: the pass is latency-bound
+                float v[16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int i = i0 + u * 64 + lane;
                     v[u] = (i < ntot) ? sc[i] : -INFINITY;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int i = i0 + u * 64 + lane;
                     if (i < ntot && v[u] >= obj_thresh) {
                         const unsigned long long k = key_of(v[u], i);
-                        cl += (k >= lo && k < hi) ? 1 : 0;
+                        if (k >= lo_c && k < hi_c) atomicAdd(&hist[(int)((k - lo_c) >> sh)], 1);
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cl += __shfl_xor(cl, o, 64);
-            return cl;
+            __syncthreads();
         };
         __shared__ int selg[256];                                 // global indices of the boxes selected so far (this wave only)
         const int *selp = (max_out <= 256) ? selg : og;
         unsigned long long hi = ~0ull;
         while (kept < max_out) {
-            unsigned long long lo = key_min;
-            int cin = count_in(lo, hi);
-            if (cin == 0) break;
-            if (cin > MAXC) {                               // invariant: count(lo_bad) > MAXC, count(lo_ok) <= MAXC
-                unsigned long long lo_bad = key_min, lo_ok = hi;
-                while (lo_ok - lo_bad > 1ull) {
-                    const unsigned long long mid = lo_bad + ((lo_ok - lo_bad) >> 1);
-                    const int cm = count_in(mid, hi);
-                    if (cm > MAXC) lo_bad = mid;
-                    else {
-                        lo_ok = mid;
-                        if (cm >= MAXC / 2) break;          // a half-full chunk is good enough
+            // ---- lo: the lowest key such that [lo, hi) holds <= MAXC candidates (a half-full chunk is good enough)
+            unsigned long long lo_c = key_min, hi_c = hi, lo = key_min;
+            if (hi_c <= lo_c) break;
+            int taken = 0;                                        // candidates in [hi_c, hi): already inside the chunk
+            for (;;) {
+                const unsigned long long range = hi_c - lo_c;                     // >= 1
+                const int bits = range > 1ull ? 64 - __builtin_clzll(range - 1ull) : 0;
+                const int sh = bits > NBL ? bits - NBL : 0;
+                const int nb = (int)(((range - 1ull) >> sh) + 1ull);              // <= NB
+                hist_pass(lo_c, hi_c, sh);
+                // walk the bins from the top: lane l owns bins nb-1-32l ... nb-32-32l (NB = 64 * 32 or 64 * 16)
+                constexpr int PER = NB / 64;
+                int mine[PER], sum = 0;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int q = nb - 1 - (lane * PER + j);
+                    mine[j] = q >= 0 ? hist[q] : 0;
+                    sum += mine[j];
+                }
+                int pre = sum;                                                    // inclusive prefix over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(pre, o, 64);
+                    if (lane >= o) pre += t;
+                }
+                const int before = pre - sum;                                     // candidates in the bins above this lane's
+                const unsigned long long cross = __ballot(taken + pre > MAXC);
+                if (cross == 0ull) {                                              // everything down to lo_c fits
+                    lo = lo_c;
+                    break;
+                }
+                const int cl = __ffsll((long long)cross) - 1;                     // the lane whose bins hold the crossing one
+                int tq = 0, tk = 0;                                               // crossing bin (counted from the top), candidates above it
+                if (lane == cl) {
+                    int run = taken + before;
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        if (run + mine[j] > MAXC) {
+                            tq = lane * PER + j;
+                            tk = run;
+                            break;
+                        }
+                        run += mine[j];
                     }
                 }
-                lo = lo_ok;
+                tq = __shfl(tq, cl, 64);
+                tk = __shfl(tk, cl, 64);
+                const int qb = nb - 1 - tq;                                       // the crossing bin's index
+                const unsigned long long b_lo = lo_c + ((unsigned long long)qb << sh), b_hi = qb + 1 >= nb ? hi_c : b_lo + (1ull << sh);
+                taken = tk;
+                if (taken >= MAXC / 2 || sh == 0) {                               // good enough / bins are single keys: the chunk ends above the crossing bin
+                    lo = b_hi;
+                    break;
+                }
+                lo_c = b_lo;                                                      // split the crossing bin
+                hi_c = b_hi;
+                // inside ONE score value the keys differ in ~index only, and ~i >= 2^32 - ntot: skip the empty part of the interval
+                // (thousands of tied scores: the next level then bins the indices directly)
+                if ((lo_c >> 32) == ((hi_c - 1ull) >> 32)) {
+                    const unsigned long long first = (lo_c & 0xffffffff00000000ull) | (0x100000000ull - (unsigned long long)ntot);
+                    if (first > lo_c && first < hi_c) lo_c = first;
+                }
+                __syncthreads();
             }
+            if (lo >= hi) break;                                                  // (cannot happen: a bin of one key holds at most one candidate)
             // gather the chunk [lo, hi): scores and indices first, boxes in bulk afterwards (no load inside the ballot chain)
             __syncthreads();
             int nc = 0;
