@@ -120,3 +120,31 @@ def test_overflow_chunks_ties_and_suppression_carried_across_chunks():
         np.testing.assert_allclose(dets[b, :30, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
     # image 0: the first box, then third-scale boxes in index order (all scores tie)
     assert dets[0, 0, 2] - dets[0, 0, 0] > 1000 and (dets[0, 1:30, 2] - dets[0, 1:30, 0] < 5).all()
+
+
+@pytest.mark.parametrize('seed,levels,conf_shift', [(0, 4, 0.0), (1, 7, 1.0), (2, 64, -1.0), (3, 2, 2.5), (4, 100000, 0.5)])
+def test_many_candidates_with_tied_scores_every_nms_path_vs_oracle(seed, levels, conf_shift):
+    """Round 6 rewrote the per-class NMS for more than 512 candidates (a bitonic sort + TF's own sweep, chunk bounds by radix select): random
+    heads of tiny_yolo's size (2 535 boxes) and of Darknet-53's (10 647) whose logits are QUANTISED to a few levels - hundreds to thousands
+    of exactly tied scores per class, so the order falls to the box index - with overlapping boxes, for candidate counts on both sides of
+    512, of the LDS capacity (2 048) and across several chunks.  Detections must equal the oracle's row for row."""
+    rng = np.random.default_rng(100 + seed)
+    for hw, in_hw in ([(13, 13), (26, 26)], (416, 416)), ([(13, 13), (26, 26), (52, 52)], (416, 416)):
+        C = 6
+        preds = []
+        for (h, w) in hw:
+            p = rng.normal(0, 1.5, (2, h, w, 3, 5 + C)).astype(np.float32)
+            q = np.round((p + conf_shift) * levels / 6.0) * 6.0 / levels                 # few distinct logits -> few distinct scores
+            p[..., 4:] = q[..., 4:]
+            p[..., 2:4] = rng.uniform(-1.0, 1.5, p[..., 2:4].shape)                      # boxes of many sizes: plenty of suppression
+            preds.append(p.astype(np.float32))
+        anchors = np.tile(ANCHORS[:1], (len(hw), 1, 1)) * np.linspace(1.0, 0.3, len(hw))[:, None, None]
+        for obj, iou in ((0.3, 0.5), (0.05, 0.3), (0.6, 0.7)):
+            dets, counts = _run(preds, anchors, in_hw, None, obj, iou)
+            ref = dr.decode_batch(preds, anchors, in_hw, in_hw, obj, iou)
+            for b in range(2):
+                rd, _ = ref[b]
+                assert counts[b] == len(rd), (hw, obj, iou, b, counts[b], len(rd))
+                d = dets[b, :counts[b]]
+                assert np.array_equal(d[:, 5], rd[:, 5])
+                np.testing.assert_allclose(d[:, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
