@@ -1842,7 +1842,12 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
         }
     }
     if ((rc = x_alloc(p, (void **)&p->d_imgmax, sizeof(unsigned) * max_batch * 32))) return fail(rc);
-    p->zero_words = (size_t)n_tensors * max_batch * XS + 2 * (size_t)max_batch * 2 * 8 * 2;   // + the barrier granules of the persistent stage and of the heads: [image][barrier parity][member] x 8 bytes each
+    // [per-image running maxima][tickets of the fused heads' K-slice reduction (yk_xfin.h)][barrier granules of the persistent stage and of the heads:
+    // [image][barrier parity][member] x 8 bytes each, addressed from the END] - everything the step's first launch clears
+    constexpr size_t XF_TICKETS = 8192;
+    const size_t ticket_base = (size_t)n_tensors * max_batch * XS;
+    size_t ticket_used = 0;
+    p->zero_words = ticket_base + XF_TICKETS + 2 * (size_t)max_batch * 2 * 8 * 2;
     if ((rc = x_alloc(p, (void **)&p->d_amax, sizeof(uint32_t) * p->zero_words))) return fail(rc);
     {   // the error word lives in mapped host memory: a failing cluster writes it over the link once, the host polls it for free
         void *h = nullptr, *d = nullptr;
@@ -2164,9 +2169,14 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                     g.slab = (float *)sl;
                     l.f.slab_bytes = (uint32_t)sb;
                 }
-                void *tk;
-                if ((rc = x_alloc(p, &tk, (size_t)(tiles + 64) * 4))) return fail(rc);
-                l.f.ticket = (uint32_t *)tk;
+                // the tile counters live in the region every step's first launch clears (the last arriver also clears its own: a step that was
+                // cut short cannot leave a count behind for the next one)
+                if (ticket_used + (size_t)tiles > XF_TICKETS) {
+                    yk_set_error("op %d: %ld head tiles: more than the %zu ticket slots of a plan; lower max_batch", i, tiles, XF_TICKETS);
+                    return fail(YK_ERR_UNSUPPORTED);
+                }
+                l.f.ticket = p->d_amax + ticket_base + ticket_used;
+                ticket_used += (size_t)tiles;
             } else {
                 int cfg;
                 if (co <= 64) cfg = Mmax >= 30000 ? XC_128x64 : XC_64x64;
