@@ -1046,7 +1046,7 @@ struct xlaunch {
     xh_args ha;                        // XK_HEADS
     unsigned h_lds = 0;
     xf_args f;                         // XK_FIN: conv + BN + act -> 1x1 output conv in one launch (yk_xfin.h)
-    int fin_bm = 64, fin_bn = 0;
+    int fin_bm = 64, fin_bn = 0, fin_nw = 4;
     int p_cw = 0;
     std::string name;
     double flops = 0, bytes = 0;
@@ -1120,26 +1120,30 @@ int x_launch_conv(int cfg, int ns, const xg_args &g, hipStream_t st) {
 }
 
 // a detection head in one launch (yk_xfin.h): grid = (BM-row tiles, 1, K slices)
-template <int BM, int BN>
+template <int BM, int BN, int NW>
 int x_launch_fin_bn(const xf_args &f, int ns, hipStream_t st) {
-    typedef xf_cfg<BM, BN> C;
+    typedef xf_cfg<BM, BN, NW> C;
     const dim3 grid((unsigned)((f.c.M + BM - 1) / BM), 1u, (unsigned)f.c.splitk);
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(2));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(3));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 2, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(xf_kernel<BM, BN, 3, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, C::lds(3));
         once = true;
     }
-    if (ns >= 3) hipLaunchKernelGGL((xf_kernel<BM, BN, 3>), grid, dim3(C::NT), (unsigned)C::lds(3), st, f);
-    else hipLaunchKernelGGL((xf_kernel<BM, BN, 2>), grid, dim3(C::NT), (unsigned)C::lds(2), st, f);
+    if (ns >= 3) hipLaunchKernelGGL((xf_kernel<BM, BN, 3, NW>), grid, dim3(C::NT), (unsigned)C::lds(3), st, f);
+    else hipLaunchKernelGGL((xf_kernel<BM, BN, 2, NW>), grid, dim3(C::NT), (unsigned)C::lds(2), st, f);
     return YK_OK;
 }
-int x_launch_fin(int bm, int bn, int ns, const xf_args &f, hipStream_t st) {
-    if (bm == 64 && bn == 128) return x_launch_fin_bn<64, 128>(f, ns, st);
-    if (bm == 64 && bn == 192) return x_launch_fin_bn<64, 192>(f, ns, st);
-    if (bm == 128 && bn == 128) return x_launch_fin_bn<128, 128>(f, ns, st);
-    if (bm == 128 && bn == 192) return x_launch_fin_bn<128, 192>(f, ns, st);
-    yk_set_error("f16x2: no fused head kernel for a %d x %d tile", bm, bn);
+int x_launch_fin(int bm, int bn, int nw, int ns, const xf_args &f, hipStream_t st) {
+    if (bm == 64 && bn == 128 && nw == 4) return x_launch_fin_bn<64, 128, 4>(f, ns, st);
+    if (bm == 64 && bn == 192 && nw == 4) return x_launch_fin_bn<64, 192, 4>(f, ns, st);
+#ifdef YK_DEV                                                           // measured equal (8 waves on a 64-row tile) or slower (128-row tiles): developer builds
+    if (bm == 64 && bn == 128 && nw == 8) return x_launch_fin_bn<64, 128, 8>(f, ns, st);
+    if (bm == 64 && bn == 192 && nw == 8) return x_launch_fin_bn<64, 192, 8>(f, ns, st);
+    if (bm == 128 && bn == 128) return x_launch_fin_bn<128, 128, 8>(f, ns, st);
+    if (bm == 128 && bn == 192) return x_launch_fin_bn<128, 192, 8>(f, ns, st);
+#endif
+    yk_set_error("f16x2: no fused head kernel for a %d x %d tile on %d waves", bm, bn, nw);
     return YK_ERR_ARG;
 }
 
@@ -2161,6 +2165,8 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 if (const char *e = yk_dev_env("YK_XF_NS")) l.ns = std::max(2, std::min(3, atoi(e)));
                 l.fin_bm = bm;
                 l.fin_bn = co;
+                l.fin_nw = bm == 128 ? 8 : 4;
+                if (const char *e = yk_dev_env("YK_XF_NW")) l.fin_nw = (atoi(e) == 8 || bm == 128) ? 8 : 4;
                 l.f.slab_bytes = 0;
                 if (g.splitk > 1) {
                     void *sl;
@@ -2256,7 +2262,7 @@ int yk_xplan_create(yk_xplan **out, const int32_t *ops, int n_ops, const int32_t
                 l.Wo = Y.w;
                 f.c = g;
                 char tl[64];
-                snprintf(tl, sizeof tl, "[%dx%d,ring%d%s]", l.fin_bm, co, l.ns, g.splitk > 1 ? ",splitk" : "");
+                snprintf(tl, sizeof tl, "[%dx%d,%dwaves,ring%d%s]", l.fin_bm, co, l.fin_nw, l.ns, g.splitk > 1 ? ",splitk" : "");
                 snprintf(nm, sizeof nm, "x:conv%dx%ds%d_%dto%d%s+conv1x1_%dto%d%s", ks, ks, g.stride, cin, co, S1 ? "+upcat" : (up0 ? "+up" : ""), co, f.N2, tl);
                 l.flops = 2.0 * Y.h * Y.w * ks * ks * (double)cin * co + 2.0 * Y.h * Y.w * (double)co * f.N2;
                 l.bytes = ((double)S0.h * S0.w * c0 + (S1 ? (double)S1->h * S1->w * c1 : 0.0) + 2.0 * Y.h * Y.w * co + (double)Y.h * Y.w * f.N2) * 4;
@@ -2475,7 +2481,7 @@ int yk_xplan_run(yk_xplan *p, const void *d_in, int in_f32, int batch, hipStream
             xf_args f = l.f;
             f.c.B = batch;
             f.c.M = batch * l.Ho * l.Wo;
-            int rc = x_launch_fin(l.fin_bm, l.fin_bn, l.ns, f, st);
+            int rc = x_launch_fin(l.fin_bm, l.fin_bn, l.fin_nw, l.ns, f, st);
             if (rc) return rc;
         } break;
         case XK_BLOCK: {

@@ -34,10 +34,10 @@ struct xf_args {
     uint32_t slab_bytes;
 };
 
-// BM = 64 (4 waves) or 128 (8 waves): wave (wm, wn) owns rows [wm*32, wm*32+32) x columns [wn*BN/2, (wn+1)*BN/2)
-template <int BM, int BN>
+// NW waves: wave (wm, wn) owns rows [wm*32, wm*32+32) x columns [wn*BN/WN, (wn+1)*BN/WN); (BM, NW) = (64, 4): 2x2 waves, (64, 8): 2x4, (128, 8): 4x2
+template <int BM, int BN, int NWV>
 struct xf_cfg {
-    static constexpr int NW = BM / 16, WM = NW / 2, WN = 2, NT = 64 * NW;
+    static constexpr int NW = NWV, WM = BM / 32, WN = NW / WM, NT = 64 * NW;
     static constexpr int TM = 2, TN = BN / WN / 16;
     static constexpr int RB = BM / 16;                            // 16-row blocks of the tile
     static constexpr int STAGE = (BM + BN) * 128;
@@ -46,12 +46,13 @@ struct xf_cfg {
     static constexpr int lds(int ns) { return (ns * STAGE > A2 ? ns * STAGE : A2) + SMALL; }
 };
 
-template <int BM, int BN, int NS>
-__global__ void __launch_bounds__(BM * 4) xf_kernel(const xf_args f) {
-    typedef xf_cfg<BM, BN> C;
+template <int BM, int BN, int NS, int NWV>
+__global__ void __launch_bounds__(64 * NWV) xf_kernel(const xf_args f) {
+    typedef xf_cfg<BM, BN, NWV> C;
     constexpr int WN = C::WN, NW = C::NW, TM = C::TM, TN = C::TN, RB = C::RB, NT = C::NT;
-    constexpr int A_IT = (BM / 16 * 2) / NW, B_IT = (BN / 16 * 2) / NW, L = A_IT + B_IT, AR = A_IT / 2;
-    static_assert(A_IT % 2 == 0 && (BN / 16 * 2) % NW == 0, "1 KB pieces must divide among the waves");
+    // A pieces: global piece p = wid*A_IT + n is (row block p >> 1, half p & 1); a wave with ONE piece fetches one half of one row block
+    constexpr int A_IT = (BM / 16 * 2) / NW, B_IT = (BN / 16 * 2) / NW, L = A_IT + B_IT, AR = (A_IT + 1) / 2;
+    static_assert((BM / 16 * 2) % NW == 0 && (BN / 16 * 2) % NW == 0 && (A_IT == 1 || A_IT % 2 == 0), "1 KB pieces must divide among the waves");
     static_assert(NS >= 2 && (NS - 2) * L <= 63, "vmcnt is a 6-bit counter");
     const xg_args &a = f.c;
     constexpr int BIG = C::lds(NS) - C::SMALL;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(BM * 4) xf_kernel(const xf_args f) {
     int ry[AR], rx[AR];
 #pragma unroll
     for (int it = 0; it < AR; ++it) {
-        const int m = m0 + (wid * AR + it) * 16 + lr;
+        const int m = m0 + ((wid * A_IT) / 2 + it) * 16 + lr;
         const bool ok = m < a.M;
         const uint32_t mm = ok ? m : 0;
         const uint32_t b = x_div(mm, a.fd_hw), rem = mm - b * a.HoWo;
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(BM * 4) xf_kernel(const xf_args f) {
         const uint32_t d_ws = live ? wbase + (uint32_t)step * wstep : X_OOB;
 #pragma unroll
         for (int n = 0; n < A_IT; ++n) {
-            const uint32_t o = aoff[n >> 1] + d_cso + (uint32_t)(n & 1) * 16u;
+            const uint32_t o = aoff[n >> 1] + d_cso + (uint32_t)((wid * A_IT + n) & 1) * 16u;
             lds_ptr_t dsta = (lds_ptr_t)(As + (wid * A_IT + n) * 1024);
             if (seg) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dsta, 16, o, 0, 0, 0);
@@ -292,48 +293,53 @@ __global__ void __launch_bounds__(BM * 4) xf_kernel(const xf_args f) {
     }
     __syncthreads();
 
-    // ---- the 1x1 output conv: wave `wid` owns rows [wid*16, wid*16+16) x all N2 columns; K = BN
+    // ---- the 1x1 output conv: wave w owns row block w % RB and N2 blocks [g*NBW, (g+1)*NBW) with g = w / RB (one group, or two: 3 + 2 blocks); K = BN
     constexpr int NB2 = 5, K2 = BN / 32;                              // 80 columns cover the 75 = 3 * (5 + 20) of a VOC head
+    constexpr int NG = NW / RB, NBW = (NB2 + NG - 1) / NG;
+    const int rb2 = wid % RB, nbb = (wid / RB) * NBW;
     const uint8_t *wq = f.w2 + foff;                                 // host order = fragment order: lane (row fr, chunk fq) reads its own 16 bytes
-    half8 bh[2][NB2], blo[2][NB2];
+    half8 bh[2][NBW], blo[2][NBW];
     auto loadb = [&](int ks, int buf) {
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-            const uint8_t *q = wq + ((size_t)ks * f.nslab2 + nb) * 2048;
-            bh[buf][nb] = *reinterpret_cast<const half8 *>(q);
-            blo[buf][nb] = *reinterpret_cast<const half8 *>(q + 1024);
+        for (int q = 0; q < NBW; ++q) {
+            const int nb = min(nbb + q, NB2 - 1);
+            const uint8_t *pq = wq + ((size_t)ks * f.nslab2 + nb) * 2048;
+            bh[buf][q] = *reinterpret_cast<const half8 *>(pq);
+            blo[buf][q] = *reinterpret_cast<const half8 *>(pq + 1024);
         }
     };
-    floatx4 acc2[NB2];
+    floatx4 acc2[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NB2; ++nb) acc2[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NBW; ++q) acc2[q] = floatx4{0.f, 0.f, 0.f, 0.f};
     loadb(0, 0);
 #pragma unroll
     for (int ks = 0; ks < K2; ++ks) {
         if (ks + 1 < K2) loadb(ks + 1, (ks + 1) & 1);
-        const half8 xh = *reinterpret_cast<const half8 *>(A2 + ((ks * RB + wid) * 2) * 1024 + foff);
-        const half8 xl = *reinterpret_cast<const half8 *>(A2 + ((ks * RB + wid) * 2 + 1) * 1024 + foff);
+        const half8 xh = *reinterpret_cast<const half8 *>(A2 + ((ks * RB + rb2) * 2) * 1024 + foff);
+        const half8 xl = *reinterpret_cast<const half8 *>(A2 + ((ks * RB + rb2) * 2 + 1) * 1024 + foff);
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo[ks & 1][nb], xh, acc2[nb], 0, 0, 0);
+        for (int q = 0; q < NBW; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo[ks & 1][q], xh, acc2[q], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks & 1][nb], xl, acc2[nb], 0, 0, 0);
+        for (int q = 0; q < NBW; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks & 1][q], xl, acc2[q], 0, 0, 0);
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks & 1][nb], xh, acc2[nb], 0, 0, 0);
+        for (int q = 0; q < NBW; ++q) acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ks & 1][q], xh, acc2[q], 0, 0, 0);
     }
     {
-        const int r = wid * 16 + fr, m = m0 + r;
+        const int r = rb2 * 16 + fr, m = m0 + r;
         const int bi = (int)x_div((uint32_t)min(a.M - 1, m), a.fd_hw) - b0;
         const float up2 = 1.0f / s_down[bi];                        // 2^e of the intermediate (a power of two: exact)
         if (m < a.M) {
             float *o = f.out32 + (size_t)m * f.N2;
 #pragma unroll
-            for (int nb = 0; nb < NB2; ++nb) {
+            for (int q = 0; q < NBW; ++q) {
+                const int nb = nbb + q;
+                if (nb >= NB2) continue;
                 const int n = nb * 16 + (lane >> 4) * 4;
                 const float4 sc = *reinterpret_cast<const float4 *>(f.scale2 + n), bs = *reinterpret_cast<const float4 *>(f.bias2 + n);
-                const float o0 = x_actf(__builtin_fmaf(acc2[nb][0] * up2, sc.x, bs.x), f.slope2, f.cap2);
-                const float o1 = x_actf(__builtin_fmaf(acc2[nb][1] * up2, sc.y, bs.y), f.slope2, f.cap2);
-                const float o2 = x_actf(__builtin_fmaf(acc2[nb][2] * up2, sc.z, bs.z), f.slope2, f.cap2);
-                const float o3 = x_actf(__builtin_fmaf(acc2[nb][3] * up2, sc.w, bs.w), f.slope2, f.cap2);
+                const float o0 = x_actf(__builtin_fmaf(acc2[q][0] * up2, sc.x, bs.x), f.slope2, f.cap2);
+                const float o1 = x_actf(__builtin_fmaf(acc2[q][1] * up2, sc.y, bs.y), f.slope2, f.cap2);
+                const float o2 = x_actf(__builtin_fmaf(acc2[q][2] * up2, sc.z, bs.z), f.slope2, f.cap2);
+                const float o3 = x_actf(__builtin_fmaf(acc2[q][3] * up2, sc.w, bs.w), f.slope2, f.cap2);
                 if (n + 0 < f.N2) o[n + 0] = o0;
                 if (n + 1 < f.N2) o[n + 1] = o1;
                 if (n + 2 < f.N2) o[n + 2] = o2;
