@@ -148,3 +148,54 @@ def test_many_candidates_with_tied_scores_every_nms_path_vs_oracle(seed, levels,
                 d = dets[b, :counts[b]]
                 assert np.array_equal(d[:, 5], rd[:, 5])
                 np.testing.assert_allclose(d[:, :5], rd[:, :5], rtol=1e-5, atol=2e-3)
+
+
+def _logit(p):
+    p = np.asarray(p, np.float64)
+    return np.log(p / (1.0 - p))
+
+
+def _heads_for_boxes(boxes_yxyx, scores, W=128.0):
+    """Logits of a two-scale head ([1,1,1,3,6] + [1,1,1,3,6], anchors 1.0, one class, 128x128 network and image) whose python-mode decode
+    gives `boxes_yxyx` (pixels, (y1, x1, y2, x2)) and `scores`, in this order: (layer, h, w, anchor) - keras_inference.py:107-108."""
+    assert len(boxes_yxyx) == 6
+    preds = []
+    for l in range(2):
+        p = np.zeros((1, 1, 1, 3, 6), np.float32)
+        for a in range(3):
+            y1, x1, y2, x2 = boxes_yxyx[l * 3 + a]
+            p[0, 0, 0, a, 0] = _logit(((x1 + x2) / 2) / W)               # x = (sigmoid(tx) + 0) / 1
+            p[0, 0, 0, a, 1] = _logit(((y1 + y2) / 2) / W)
+            p[0, 0, 0, a, 2] = np.log((x2 - x1) / W)                     # w = exp(tw) * anchor (1.0), relative to the image
+            p[0, 0, 0, a, 3] = np.log((y2 - y1) / W)
+            p[0, 0, 0, a, 4] = 30.0                                      # sigmoid == 1.0 in fp32
+            p[0, 0, 0, a, 5] = _logit(scores[l * 3 + a])
+        preds.append(p)
+    return preds
+
+
+@pytest.mark.parametrize('max_out,want', [(3, [3, 0, 5]), (2, [3, 0]), (30, [3, 0, 5])])
+def test_tensorflows_own_nms_known_answers_through_the_hip_kernel(max_out, want):
+    """tf.image.non_max_suppression's published test vectors (tensorflow/core/kernels/non_max_suppression_op_test.cc:
+    TestSelectFromThreeClusters / AtMostTwoBoxes / AtMostThirtyBoxes; the same six boxes in image_ops_test.py) pushed through the whole
+    python-mode path on the GPU: logits -> decode -> `>=` mask -> per-class NMS -> compaction, with the box INDEX of every kept row.
+    (The x axis is shifted by +1 pixel: a box centre must lie inside the image for the sigmoid; IoU does not care.)"""
+    import torch
+    from k210_yolo_framework_amd import engine
+    boxes = np.array([[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9], [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]], np.float64)
+    boxes[:, [1, 3]] += 1.0
+    boxes[:, [0, 2]] += 1.0
+    scores = np.array([.9, .75, .6, .95, .5, .3])
+    preds = _heads_for_boxes(boxes, scores)
+    anchors = np.ones((2, 3, 2))
+    cfg = engine.make_decode_cfg(anchors, 1, (128, 128), [(1, 1), (1, 1)])
+    dev = [torch.from_numpy(p.reshape(1, 1, 1, -1)).cuda() for p in preds]
+    dets, counts, index = engine.decode_py(cfg, dev, 1, None, 0.2, 0.5, max_out, return_index=True)
+    torch.cuda.synchronize()
+    n = int(counts[0])
+    assert index[0, :n].cpu().tolist() == want
+    d = dets[0, :n].cpu().numpy()
+    np.testing.assert_allclose(d[:, :4], boxes[want], atol=2e-3)
+    np.testing.assert_allclose(d[:, 4], scores[want], atol=1e-6)
+    ref, ridx = dr.decode_batch(preds, anchors, (128, 128), (128, 128), 0.2, 0.5, max_out)[0]
+    assert ridx.tolist() == want

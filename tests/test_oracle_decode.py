@@ -119,3 +119,31 @@ def test_c_nms_helper_is_bit_equal_to_the_python_restatement(seed, obj, iou):
     for (wr, wi), (gr, gi) in zip(want, got):
         assert wr.shape == gr.shape and np.array_equal(wr.view(np.uint32), gr.view(np.uint32))
         assert np.array_equal(wi, gi)
+
+
+# ---- the third-party kernel behind keras_inference.py:125 (tf.image.non_max_suppression, TensorFlow 1.14, un-vendored): its OWN published
+# known-answer tests, restated from tensorflow/core/kernels/non_max_suppression_op_test.cc (NonMaxSuppressionOpTest; the same boxes and
+# scores are tensorflow/python/ops/image_ops_test.py::NonMaxSuppressionTest.testSelectFromThreeClusters).  Boxes are (y1, x1, y2, x2).
+_TF_BOXES = np.array([[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9], [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]], np.float32)
+_TF_SCORES = np.array([.9, .75, .6, .95, .5, .3], np.float32)
+
+
+@pytest.mark.parametrize('name,boxes,scores,max_out,iou,want', [
+    ('TestSelectFromThreeClusters', _TF_BOXES, _TF_SCORES, 3, 0.5, [3, 0, 5]),
+    ('TestSelectFromThreeClustersFlippedCoordinates',
+     np.array([[1, 1, 0, 0], [0, 0.1, 1, 1.1], [0, .9, 1, -0.1], [0, 10, 1, 11], [1, 10.1, 0, 11.1], [1, 101, 0, 100]], np.float32), _TF_SCORES, 3, 0.5,
+     [3, 0, 5]),
+    ('TestSelectAtMostTwoBoxesFromThreeClusters', _TF_BOXES, _TF_SCORES, 2, 0.5, [3, 0]),
+    ('TestSelectWithNegativeScores', _TF_BOXES, _TF_SCORES - np.float32(10.0), 6, 0.5, [3, 0, 5]),
+    ('TestSelectAtMostThirtyBoxesFromThreeClusters', _TF_BOXES, _TF_SCORES, 30, 0.5, [3, 0, 5]),
+    ('TestSelectSingleBox', np.array([[0, 0, 1, 1]], np.float32), np.array([.9], np.float32), 3, 0.5, [0]),
+    ('TestSelectFromTenIdenticalBoxes', np.tile(np.array([[0, 0, 1, 1]], np.float32), (10, 1)), np.full(10, .9, np.float32), 3, 0.5, [0]),
+    ('TestEmptyInput', np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 30, 0.5, []),
+])
+def test_nms_restatement_against_tensorflows_own_known_answer_tests(name, boxes, scores, max_out, iou, want):
+    """Pins oracle/decode_ref.non_max_suppression (and, through tests/test_gpu_decode.py's exact row-for-row comparisons, the HIP kernel) to
+    the vectors TensorFlow itself tests this kernel with: greedy in descending score order, IoU on min/max-normalised corners (flipped
+    coordinates), strict `>`, the cap, negative scores, identical boxes collapsing to the first."""
+    assert dr.non_max_suppression(boxes, scores, max_out, iou) == want, name
+    # the answer follows the boxes, not their positions: the reversed input gives the mirrored indices (identical boxes: the first again)
+    assert dr.non_max_suppression(boxes[::-1].copy(), scores[::-1].copy(), max_out, iou) == [len(scores) - 1 - k for k in want] or name == 'TestSelectFromTenIdenticalBoxes'
