@@ -481,6 +481,9 @@ def main():
 
         def step(self):
             if self.from_host:
+                # every slot's frames wait in pinned memory: the copy of the NEXT submit's batch is started before this one is launched
+                # (Pipeline.stage_host: what a producer thread does when it has filled a slot) - each batch still crosses PCIe inside the timed region
+                self.pipe.stage_host(self.pipe.next_slot() + 1)
                 return self.pipe.submit_host(None)
             return self.pipe.submit(self.src, sync_input=False)   # resident frames: nothing to order them behind
 

@@ -532,6 +532,7 @@ class Pipeline:
             s.h2d_bufs = [s.src, torch.full_like(s.src, 127)]
             s.h2d_next = 0
             s.h2d_copied = [torch.cuda.Event(), torch.cuda.Event()]
+            s.staged = None                                         # (buffer index, batch) of a copy stage_host() has started
             s.h2d_free = [None, None]
             if self._copy_stream is None:
                 if self._own_streams:                                   # library-created, like the slots' streams
@@ -544,29 +545,52 @@ class Pipeline:
                     self._copy_stream = torch.cuda.Stream(device=s.src.device)
 
     # -- the step, as the library calls it is made of (eager, or recorded by capture()) ---------------------------------
-    def _h2d(self, s, B):
-        """The host -> device leg, issued EAGERLY in front of the replay (measured, images/s from host with four batches in flight: copy
-        engine in front of the replay 66 k; as a copy node inside the captured step 55 k; as a kernel inside it that reads the pinned
-        frames through their device alias 54 k; everything eager 74 k - profiles/r04_schedules.txt) - and, since round 5, on the pipeline's
-        COPY stream into the slot's other input buffer: it waits for the batch that last read that buffer, the slot's stream waits for it.
-        -> the device address the step reads."""
+    def _h2d_start(self, s, B):
+        """Issue the host -> device copy of slot `s`'s pinned frames into its other device input buffer, on the pipeline's COPY stream (the copy of
+        a slot's next batch runs under its current batch's kernels).  -> the buffer's index; `s.h2d_copied[b]` fires when the frames are there."""
+        import time
         b = s.h2d_next
         s.h2d_next ^= 1
         dst, cs = s.h2d_bufs[b], self._copy_stream
         if s.h2d_free[b] is not None and not s.h2d_free[b].query():
             # the batch that last read this buffer (two submits of this slot ago) - waited for on the HOST, where it is over long ago in steady
             # state: a wait inside the copy stream would put barrier packets into a fifth hardware queue, and a fifth active queue costs the
-            # four compute streams a quarter of their rate (DESIGN.md 0.0: the part has four compute pipes; measured 85 -> 61 k images/s)
-            import time
+            # four compute streams a quarter of their rate (measured 85 -> 61 k images/s)
             t0 = time.perf_counter()
             s.h2d_free[b].synchronize()
             self.host_wait_us += (time.perf_counter() - t0) * 1e6      # blocked, not busy: bench.py reports the two apart
         _check(lib().yk_memcpy_async(C.c_void_p(dst.data_ptr()), C.c_void_p(s.h_src.data_ptr()), C.c_size_t(B * s.src[0].numel()),
                                      C.c_void_p(cs.cuda_stream)), 'yk_memcpy_async')
         s.h2d_copied[b].record(cs)
-        s.stream.wait_event(s.h2d_copied[b])
+        return b
+
+    def stage_host(self, i: Optional[int] = None, batch: Optional[int] = None) -> None:
+        """The frames in host_input(i) are final (default: the slot of the next submit): start their copy to the device NOW, so that it runs
+        while earlier batches compute and `submit_host(None)` of that slot finds it done.  A producer calls this when it has filled a slot;
+        bench.py calls it one submit ahead.  Optional: without it submit_host issues the copy itself."""
+        s = self.slots[(self._n if i is None else int(i)) % self.depth]
+        self._host_side(s)
+        B = self.max_batch if batch is None else int(batch)
+        if getattr(s, 'staged', None) is None:
+            s.staged = (self._h2d_start(s, B), B)
+
+    def _h2d(self, s, B):
+        """The host -> device leg, issued EAGERLY in front of the replay (measured, images/s from host with four batches in flight: copy
+        engine in front of the replay 66 k; as a copy node inside the captured step 55 k; as a kernel inside it that reads the pinned
+        frames through their device alias 54 k - profiles/r04_schedules.txt) on the pipeline's COPY stream into the slot's other input buffer.
+        The step is launched when the HOST has seen the copy finish (round 6: tools/from_host_split.py, one box, resident 99.7 k: the slot's
+        stream waiting for the copy's event 91.4 k - a cross-queue barrier packet per step; the host waiting 92.5 k; the host waiting for a copy
+        that stage_host() started one submit earlier 94.8 k = what the copy traffic alone costs).  -> the device address the step reads."""
+        import time
+        st = getattr(s, 'staged', None)
+        s.staged = None
+        b = st[0] if st is not None and st[1] == B else self._h2d_start(s, B)
+        if not s.h2d_copied[b].query():
+            t0 = time.perf_counter()
+            s.h2d_copied[b].synchronize()
+            self.host_wait_us += (time.perf_counter() - t0) * 1e6
         s.h2d_last = b
-        return dst.data_ptr()
+        return s.h2d_bufs[b].data_ptr()
 
     def _h2d_done(self, s):
         """After the step has been given to the slot's stream: its input buffer is free once the stream gets here."""
@@ -708,6 +732,7 @@ class Pipeline:
             B = int(f.shape[0])
             for ev in s.h2d_copied:                                     # the slot's previous copies may still be reading h_src
                 ev.synchronize()
+            s.staged = None                                             # (a copy staged from the buffer's previous contents is not this batch)
             s.h_src[:B].copy_(f)
         assert 0 < B <= self.max_batch
         use_hw = self._set_hw(s, B, image_hw)
