@@ -34,7 +34,7 @@ def timed(fn, pipe):
 
 
 res = {}
-for mode in ('resident', 'h2d_only', 'h2d_hostwait', 'h2d_hostwait_prefetch', 'from_host', 'from_host_hostwait', 'resident'):
+for mode in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('resident', 'h2d_only', 'h2d_hostwait', 'h2d_hostwait_prefetch', 'from_host', 'from_host_hostwait', 'resident')):
     pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=B, depth=4, precision='f16x2', graph=True)
     for i in range(4):
         pipe.host_input(i).copy_(frames.cpu())
@@ -98,6 +98,32 @@ for mode in ('resident', 'h2d_only', 'h2d_hostwait', 'h2d_hostwait_prefetch', 'f
             else:
                 pipe._run(s, B, s.h2d_bufs[b].data_ptr(), False, False, 0.7, 0.5, 30, False)
             ev = torch.cuda.Event(); ev.record(s.stream); s.h2d_free[b] = ev
+    elif mode.startswith('copy_'):
+        import ctypes as C
+        L = engine.lib()
+        pipe._host_side(pipe.slots[0])
+        scratch = torch.empty((2, B, 224, 320, 3), dtype=torch.uint8, device='cuda')
+        src_d = torch.randint(0, 255, (B, 224, 320, 3), dtype=torch.uint8, device='cuda')
+        nb = B * 224 * 320 * 3
+        kinds = {'copy_h2d': (pipe.slots[0].h_src.data_ptr(), nb, 1), 'copy_half': (pipe.slots[0].h_src.data_ptr(), nb // 2, 1),
+                 'copy_2x': (pipe.slots[0].h_src.data_ptr(), nb, 2), 'copy_d2d': (src_d.data_ptr(), nb, 1), 'copy_tiny': (pipe.slots[0].h_src.data_ptr(), 4096, 1)}
+        for nch in (2, 3, 4, 8, 16):
+            kinds[f'copy_chunks{nch}'] = (pipe.slots[0].h_src.data_ptr(), nb, -nch)
+        srcp, nbytes, reps = kinds[mode]
+        cnt = [0]
+
+        def fn():
+            if reps < 0:                                               # the same bytes as -reps back-to-back copies
+                n = -reps
+                per = (nbytes + n - 1) // n
+                for r in range(n):
+                    o = r * per
+                    L.yk_memcpy_async(C.c_void_p(scratch[cnt[0] & 1].data_ptr() + o), C.c_void_p(srcp + o), C.c_size_t(min(per, nbytes - o)), C.c_void_p(pipe._copy_stream.cuda_stream))
+            else:
+                for r in range(reps):                                  # traffic only: nobody reads the destination, nobody waits
+                    L.yk_memcpy_async(C.c_void_p(scratch[(cnt[0] + r) & 1].data_ptr()), C.c_void_p(srcp), C.c_size_t(nbytes), C.c_void_p(pipe._copy_stream.cuda_stream))
+            cnt[0] += 1
+            pipe.submit(frames, sync_input=False)
     elif mode == 'h2d_only':
         def fn():
             s = pipe.slots[pipe._n % pipe.depth]
