@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     int *og = sel_g + ((size_t)b * C + c) * max_out;
     float *os = sel_s + ((size_t)b * C + c) * max_out;
     int n = 0;
+    float cmin = INFINITY, cmax = -INFINITY;                          // candidate score range: all equal = the order is the box index = the scan order
     for (int base0 = 0; base0 < ntot; base0 += 64 * 8) {
         float sv[8];                                                  // 8 independent loads in flight
 #pragma unroll
@@ -112,9 +113,19 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
                 L.s[pos] = sv[u];
                 L.idx[pos] = i;
             }
+            if (f) {
+                cmin = fminf(cmin, sv[u]);
+                cmax = fmaxf(cmax, sv[u]);
+            }
             n += __popcll(m);
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cmin = fminf(cmin, __shfl_xor(cmin, o, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+    }
+    const bool all_tied = n > 0 && cmin == cmax;
     __syncthreads();
     // boxes of the candidates, fetched in bulk AFTER the scan: a load inside the ballot loop above would put one global
     // round trip on the critical path per unrolled step (measured: 24 serialised latencies, ~40 us of a 53 us kernel)
@@ -145,10 +156,12 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
     const bool q_guard = iou_thresh > 0.f;
     const float q_hi = q_guard ? iou_thresh * (1.f + 2e-6f) : INFINITY, q_lo = q_guard ? iou_thresh * (1.f - 2e-6f) : -INFINITY;
     const bool sweep_ok = max_out <= 64 && ntot < (1 << 20);
-    auto sorted_sweep = [&](int nc) {
+    auto sorted_sweep = [&](int nc, bool presorted) {
+        // presorted: the LDS arrays already ARE in key order (every score ties: order = box index = scan order): no sort, keys built in place
         unsigned long long *key = reinterpret_cast<unsigned long long *>(L.s);      // L.s and L.idx are adjacent: 8 bytes per candidate
         int P = 64;
-        while (P < nc) P <<= 1;                                                     // (callers make sure P <= MAXC)
+        while (P < nc && !presorted) P <<= 1;                                       // (callers make sure P <= MAXC)
+        if (presorted) P = nc;
         constexpr int PL = (MAXC + 63) / 64;
         uint32_t sv_[PL], iv_[PL];
 #pragma unroll
@@ -168,7 +181,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             }
         }
         __syncthreads();
-        for (int k = 2; k <= P; k <<= 1)
+        for (int k = 2; k <= P && !presorted; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int t = lane; t < (P >> 1); t += 64) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
@@ -292,8 +305,57 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
                 }
             }
         }
+    } else if (all_tied && sweep_ok) {
+        // every candidate has the SAME score (saturated logits: what the random-init Darknet-53 of the benchmark produces, 1 000 - 10 647
+        // candidates per class at exactly 1.0): descending (score, -index) order is ascending box index, which is the order the scan
+        // compacted them in.  The LDS already holds the first chunk, sorted; later chunks are the next MAXC candidates of the same scan.
+        int done = 0;
+        for (;;) {
+            const int nc = min(n - done, MAXC);
+            sorted_sweep(nc, true);
+            done += nc;
+            if (kept >= max_out || done >= n) break;
+            __syncthreads();
+            int seen = 0;                                             // candidates ranked [done, done + MAXC) in scan order
+            for (int base0 = 0; base0 < ntot; base0 += 64 * 8) {
+                float sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base0 + u * 64 + lane;
+                    sv[u] = (i < ntot) ? sc[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base0 + u * 64 + lane;
+                    const bool f = (i < ntot) && (sv[u] >= obj_thresh);
+                    const unsigned long long m = __ballot(f);
+                    const int pos = seen + __popcll(m & ((1ull << lane) - 1ull)) - done;
+                    if (f && pos >= 0 && pos < MAXC) {
+                        L.s[pos] = sv[u];
+                        L.idx[pos] = i;
+                    }
+                    seen += __popcll(m);
+                }
+            }
+            __syncthreads();
+            const int nn = min(n - done, MAXC);
+            for (int c0 = 0; c0 < nn; c0 += 256) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = c0 + u * 64 + lane;
+                    t[u] = bx[q < nn ? L.idx[q] : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = c0 + u * 64 + lane;
+                    if (q < nn) L.box[q] = t[u];
+                }
+            }
+            __syncthreads();
+        }
     } else if (n <= MAXC && sweep_ok && (n <= 1024 ? 1024 : 2048) <= MAXC) {
-        sorted_sweep(n);
+        sorted_sweep(n, false);
     } else if (n <= MAXC) {
         kept = yk_wave_greedy_nms(
             n, L.s, L.idx, L.box, iou_thresh, max_out, [](const float4 &a, const float4 &d) { return tf_iou(d, a); },
@@ -451,7 +513,7 @@ __global__ void __launch_bounds__(64) nms_py_kernel(int ntot, int C, float obj_t
             }
             __syncthreads();
             if (sweep_ok && MAXC >= 2048) {                           // sorted sweep: the selected boxes carry over in registers
-                sorted_sweep(min(nc, MAXC));
+                sorted_sweep(min(nc, MAXC), false);
                 if (lo == key_min) break;
                 hi = lo;
                 continue;
