@@ -19,7 +19,8 @@
 //               registers (host order = fragment order), K = N; + bias; fp32 rows of the network output.
 //
 // Arithmetic order per output element is the unfused path's (k-steps ascending, w_lo*x_hi, w_hi*x_lo, w_hi*x_hi; slices in z order): with
-// the same `splitk` the logits are bit-identical to the three-launch form (tests/test_gpu_heads.py).
+// the same slice counts (7 and 4 at 32 images: the developer build's YK_XF_SPLITK_192 / _128) the logits ARE bit-identical to the three-launch form
+// (tests/test_gpu_fin.py::test_equal_slice_counts_give_bit_identical_logits); the shipped rule slices differently: 2e-6 of scale apart.
 #pragma once
 
 struct xf_args {

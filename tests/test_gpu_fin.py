@@ -88,3 +88,33 @@ def test_other_networks_and_sizes_agree_with_their_unfused_plans():
             assert np.isfinite(x).all(), name
             assert np.abs(x - y).max() <= tol * np.abs(y).max(), name
     assert taken >= 6
+
+
+@pytest.mark.skipif('dev' not in os.path.basename(os.environ.get('YK_LIB_PATH', '')),
+                    reason='needs the slice-count override of the developer build (YK_LIB_PATH=.../libyolo_hip_dev.so)')
+def test_equal_slice_counts_give_bit_identical_logits():
+    """The fused head keeps the unfused path's arithmetic order per output element (k-steps ascending, three products per step, slices in z order,
+    the same storage exponent for the tensor between the two convs): with the three-launch form's slice counts (7 and 4 at 32 images) its
+    logits are BIT-identical to it."""
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec = ns.yolo_mobilev1((224, 320, 3), 3, 20, alpha=0.75)
+    w = spec.init_weights(seed=1)
+    frames = np.random.default_rng(0).integers(0, 256, (32, 224, 320, 3), dtype=np.uint8)
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            plan = engine.Plan(spec, w, max_batch=32, precision='f16x2', schedule='throughput')
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        plan.run_u8(torch.from_numpy(frames).cuda())
+        plan.check()
+        o = [x.cpu().numpy().copy() for x in plan.outputs()]
+        plan.close()
+        return o
+    a = run({'YK_XF_SPLITK_192': '7', 'YK_XF_SPLITK_128': '4'})
+    b = run({'YK_FUSE_HEAD': '0'})
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
