@@ -91,6 +91,55 @@ def test_from_host_ticket_delivers_the_concatenated_detections():
         pipe.close()
 
 
+def test_staged_host_copy_gives_the_same_rows_and_is_dropped_when_frames_are_passed():
+    """Pipeline.stage_host starts a slot's host -> device copy ahead of its submit (bench.py's from-host leg does this one submit ahead).
+    The rows must equal those of an unstaged submit; frames handed over at submit time replace a copy staged from the buffer's old contents;
+    a staged batch size that differs from the submit's is not used."""
+    import torch
+    from k210_yolo_framework_amd import engine
+    spec, w = _net()
+    B = 5
+    rng = np.random.default_rng(11)
+    batches = [rng.integers(0, 256, (B, 224, 320, 3), dtype=np.uint8) for _ in range(4)]
+    for graph in (False, True):
+        pipe = engine.Pipeline(spec, w, VOC_ANCHORS, max_batch=8, depth=2, graph=graph)
+        want = []
+        for f in batches:
+            rows, off = pipe.submit_host(f).result()
+            want.append((rows.copy(), off.copy()))
+        assert sum(len(r) for r, _ in want) > 0
+        for rnd in range(2):
+            # the producer fills the slot AFTER the next one and stages it, then submits the next one: one copy always runs ahead
+            tickets, got = [], {}
+            i0 = pipe.next_slot()
+            pipe.host_input(i0)[:B].copy_(torch.from_numpy(batches[0]))
+            pipe.stage_host(i0, batch=B)
+            for k in range(len(batches)):
+                if k + 1 < len(batches):
+                    i1 = pipe.next_slot() + 1
+                    if k + 1 >= pipe.depth:
+                        got[k + 1 - pipe.depth] = tuple(a.copy() for a in tickets[k + 1 - pipe.depth].result())   # consume the slot's previous batch before refilling it
+                    pipe.host_input(i1)[:B].copy_(torch.from_numpy(batches[k + 1]))
+                    pipe.stage_host(i1, batch=B)
+                tickets.append(pipe.submit_host(None, batch=B))
+            for k, t in enumerate(tickets):
+                rows, off = got[k] if k in got else t.result()
+                assert np.array_equal(off, want[k][1]) and np.array_equal(rows, want[k][0]), (graph, rnd, k)
+        # a staged copy of stale contents is dropped when the submit brings its own frames
+        i0 = pipe.next_slot()
+        pipe.host_input(i0)[:B].copy_(torch.from_numpy(batches[3]))
+        pipe.stage_host(i0, batch=B)
+        rows, off = pipe.submit_host(batches[1]).result()
+        assert np.array_equal(off, want[1][1]) and np.array_equal(rows, want[1][0])
+        # a copy staged for another batch size is not used: the submit copies what it needs itself
+        i0 = pipe.next_slot()
+        pipe.host_input(i0)[:B].copy_(torch.from_numpy(batches[2]))
+        pipe.stage_host(i0, batch=2)
+        rows, off = pipe.submit_host(None, batch=B).result()
+        assert np.array_equal(off, want[2][1]) and np.array_equal(rows, want[2][0])
+        pipe.close()
+
+
 def test_letterboxing_pipeline_equals_letterbox_then_run():
     import torch
     from k210_yolo_framework_amd import engine
