@@ -329,6 +329,16 @@ int yk_bn_train_fwd_f32(const float *z, long long M, int C, const float *gamma, 
 int yk_bn_train_fwd_res_f32(const float *z, long long M, int C, const float *gamma, const float *beta, float eps, int act,
                             float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
                             float *moving_var, float momentum, const float *res, void *stream);
+/* Conv2D / DepthwiseConv2D + BatchNormalization(training=True) + activation (+ residual) forward in ONE call: z = the convolution
+ * (X [M][K] row-major with leading dimension ldx, W [N][K]: 1x1 convs directly, 3x3 through yk_im2col3x3_f32), y as yk_bn_train_fwd_res_f32.
+ * The producer of z leaves the partial sums of the batch statistics, so z is not read again for them.  Same arithmetic per element as the
+ * separate calls; the statistics are added in another (fixed) order in double. */
+int yk_gemm_bn_fwd_f32(int M, int N, int K, const float *X, int ldx, const float *W, int ldw, float *z, const float *gamma, const float *beta,
+                       float eps, int act, float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
+                       float *moving_var, float momentum, const float *res, void *stream);
+int yk_dw3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                        float *z, const float *gamma, const float *beta, float eps, int act, float alpha, float *y, float *save_mean,
+                        float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream);
 int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M, int C, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_invstd, int act, float alpha, float *dz, float *dgamma,
                         float *dbeta, void *stream);

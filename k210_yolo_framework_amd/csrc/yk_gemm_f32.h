@@ -14,7 +14,9 @@
 // MFMA-bound once the loads are hidden.
 #pragma once
 
-template <bool TA, bool TB, bool VEC>
+// STATS (forward of a conv followed by BatchNormalization, unsplit K): the epilogue also leaves the column sums of its 64 rows of C -
+// sum and sum of squares in double, partial[(m tile * 2 + {0,1}) * N + n] - so the batch statistics need no second pass over C.
+template <bool TA, bool TB, bool VEC, bool STATS = false>
 __global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
     constexpr int BK = 32, LDM = 34, LDK = 80;
     constexpr int SA = TA ? BK * LDK : 64 * LDM, SB = TB ? 64 * LDM : BK * LDK;      // floats per operand tile
@@ -146,6 +148,37 @@ __global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
                     if (n + r < g.N) c[r] = slab ? v[r] : g.alpha * v[r] + (g.beta != 0.f ? g.beta * c[r] : 0.f);
             }
         }
+    if constexpr (STATS) {
+        // the tile through LDS (the operand buffers are free: the k loop ended on a barrier): thread (column n, row quarter q) adds 16 rows,
+        // the four quarters are added in order.  Rows past M hold zeros (their A rows were loaded as zeros).
+        constexpr int LT = 65;
+        float *tile = lds;
+        double *red = reinterpret_cast<double *>(lds + 64 * LT);
+        static_assert(64 * LT % 2 == 0 && 64 * LT + 2 * 2 * 4 * 64 <= 2 * (SA + SB), "statistics staging fits the operand buffers");
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(wm * 32 + i * 16 + fr) * LT + wn * 32 + j * 16 + fq * 4 + r] = acc[j][i][r] * g.alpha;
+        __syncthreads();
+        const int n = tid & 63, q = tid >> 6;
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const double v = (double)tile[(q * 16 + m) * LT + n];
+            s0 += v;
+            s1 += v * v;
+        }
+        red[(0 * 4 + q) * 64 + n] = s0;
+        red[(1 * 4 + q) * 64 + n] = s1;
+        __syncthreads();
+        if (tid < 128) {
+            const int jj = tid >> 6;
+            const double t = ((red[(jj * 4 + 0) * 64 + n] + red[(jj * 4 + 1) * 64 + n]) + red[(jj * 4 + 2) * 64 + n]) + red[(jj * 4 + 3) * 64 + n];
+            if (n0 + n < g.N) g.stats[((size_t)blockIdx.x * 2 + jj) * g.N + n0 + n] = t;
+        }
+    }
 }
 
 template <bool TA, bool TB>
@@ -155,4 +188,11 @@ static void launch_gemm_v2(const gemm_args &g, dim3 grid, hipStream_t st) {
     const bool vec = va && vb && g.lda % 4 == 0 && g.ldb % 4 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0;
     if (vec) hipLaunchKernelGGL((gemm_f32_v2_kernel<TA, TB, true>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_v2_kernel<TA, TB, false>), grid, dim3(256), 0, st, g);
+}
+
+// forward with the statistics epilogue (unsplit K, alpha = 1, beta = 0)
+static void launch_gemm_fwd_stats(const gemm_args &g, dim3 grid, hipStream_t st) {
+    const bool vec = g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((gemm_f32_v2_kernel<false, true, true, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_v2_kernel<false, true, false, true>), grid, dim3(256), 0, st, g);
 }

@@ -27,6 +27,7 @@ struct gemm_args {
     float alpha, beta;
     const float *A, *B;
     float *C, *ws;
+    double *stats;                       // forward + BatchNormalization: column partials of C per m tile (yk_gemm_f32.h), or null
 };
 
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const gemm_args g) {
@@ -153,15 +154,7 @@ __global__ void __launch_bounds__(256) splitk_sum16_kernel(const float *__restri
 
 #include "yk_gemm_f32.h"
 
-extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B,
-                           int ldb, float beta, float *C, int ldc, void *stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) {
-        yk_set_error("yk_gemm_f32: bad argument");
-        return YK_ERR_ARG;
-    }
-    gemm_args g;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
-    g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
+static int gemm_splits(int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
     const int nk = (K + 15) / 16;
     int s = 1;
@@ -172,6 +165,19 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
         // K = 286 720 rows ran on 64 workgroups at 0.9 TB/s); 16 lanes per output fold the slabs in the finishing pass
         if (s > 512) s = 512;
     }
+    return s;
+}
+
+extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B,
+                           int ldb, float beta, float *C, int ldc, void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) {
+        yk_set_error("yk_gemm_f32: bad argument");
+        return YK_ERR_ARG;
+    }
+    gemm_args g;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
+    g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C; g.stats = nullptr;
+    const int s = gemm_splits(M, N, K);
     g.splitk = s;
     g.ws = nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -662,18 +668,33 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(const float *__restri
     }
 }
 // one wavefront per channel folds the chunk partials
+// WPC = waves per channel: 1 -> four channels per workgroup; 4 -> one channel per workgroup, the four wave sums added in order (the
+// statistics epilogue of the GEMM leaves one partial per 64 rows: 4 480 of them for the 112x160 layers at 16 images)
+template <int WPC>
 __global__ void __launch_bounds__(256) bn_stats_finish_kernel(const double *__restrict__ partial, int chunks, int C, double invM, float eps,
                                                               float *__restrict__ mean, float *__restrict__ invstd,
                                                               float *__restrict__ mm, float *__restrict__ mv, float mom) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ double wsum[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = WPC == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (c >= C) return;
     double a = 0, b = 0;
-    for (int k = lane; k < chunks; k += 64) {
+    for (int k = WPC == 1 ? lane : (int)threadIdx.x; k < chunks; k += 64 * WPC) {
         a += partial[((size_t)k * 2 + 0) * C + c];
         b += partial[((size_t)k * 2 + 1) * C + c];
     }
     a = wave_sum(a);
     b = wave_sum(b);
+    if (WPC > 1) {
+        if (lane == 0) {
+            wsum[0][wave] = a;
+            wsum[1][wave] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        a = ((wsum[0][0] + wsum[0][1]) + wsum[0][2]) + wsum[0][3];
+        b = ((wsum[1][0] + wsum[1][1]) + wsum[1][2]) + wsum[1][3];
+    }
     if (lane == 0) {
         const double mu = a * invM;
         double var = b * invM - mu * mu;                 // biased (population) variance, as tf.nn.moments
@@ -782,7 +803,7 @@ static int bn_train_fwd(const float *z, long long M, int C, const float *gamma, 
     hipLaunchKernelGGL(bn_colreduce_kernel<true>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, (const float *)nullptr,
                        (size_t)M, C, rpc, cwl, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
                        0.f, (void *)partial);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const double *)partial, chunks, C, 1.0 / (double)M, eps,
+    hipLaunchKernelGGL(bn_stats_finish_kernel<1>, dim3((C + 3) / 4), dim3(256), 0, st, (const double *)partial, chunks, C, 1.0 / (double)M, eps,
                        save_mean, save_invstd, moving_mean, moving_var, momentum);
     const size_t total = (size_t)M * C;
     if (C % 4 == 0)
@@ -817,6 +838,192 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
                            save_invstd, gamma, beta, (const float *)dbeta, (const float *)dgamma, act, alpha, dz);
     YK_HIP(hipGetLastError());
     return YK_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Conv + BatchNormalization forward in one call (round 6): the producer of z leaves the column partials of the batch statistics, so the
+// tensor is not read a second time for them (bn_colreduce_kernel<true>: 57 launches, 0.43 ms of the configs[3] step).
+//   unsplit GEMM       -> statistics epilogue per 64-row tile (yk_gemm_f32.h)
+//   split-K GEMM       -> the pass that adds the K slices writes z and the partials (below)
+//   depthwise 3x3      -> computed in the reduction's own layout (channel lanes x row lanes), partials from registers
+// then bn_stats_finish_kernel and the apply pass as in yk_bn_train_fwd_f32.
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_sum_stats_kernel(const float *__restrict__ ws, int splits, size_t M, int N, float *__restrict__ c, int ldc,
+                                                               int rows_per_chunk, int cw_log2, double *__restrict__ partial) {
+    __shared__ double red[2][256];
+    const int CW = 1 << cw_log2, RL = 256 >> cw_log2;
+    const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_log2;
+    const int n = blockIdx.y * CW + cl;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const size_t tot = M * (size_t)N;
+    double s0 = 0, s1 = 0;
+    if (n < N)
+        for (size_t m = r0 + rl; m < r1; m += RL) {
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += ws[(size_t)z * tot + m * N + n];
+            c[m * ldc + n] = v;
+            s0 += (double)v;
+            s1 += (double)v * (double)v;
+        }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        double a = 0, b = 0;
+        for (int k = 0; k < RL; ++k) {
+            a += red[0][k * CW + cl];
+            b += red[1][k * CW + cl];
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * N + n] = a;
+        partial[((size_t)blockIdx.x * 2 + 1) * N + n] = b;
+    }
+}
+
+// block = CW channel-vector lanes x RL row lanes (CW = C / V when that fits one workgroup: any number, not a power of two - 36 float4 lanes x 7
+// rows for the 144-channel layers); grid (row chunks, channel groups).  A thread keeps its 9 x V weights in registers and walks rows rl, rl + RL, ...
+template <int V>
+__global__ void __launch_bounds__(256) dw_fwd_stats_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                           int rows_per_chunk, int CW, int RL, double *__restrict__ partial) {
+    __shared__ double red[2][256][V];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = (blockIdx.y * CW + cl) * V;
+    const uint32_t M = (uint32_t)q.B * q.Ho * q.Wo;
+    const uint32_t r0 = blockIdx.x * (uint32_t)rows_per_chunk, r1 = min(M, r0 + (uint32_t)rows_per_chunk);
+    const bool on = rl < RL && c < q.C;
+    double s0[V], s1[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0;
+    if (on) {
+        float wv[9][V];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ldv<V>(w + t * q.C + c, wv[t]);
+        for (uint32_t m = r0 + rl; m < r1; m += RL) {
+            const uint32_t row = m / (uint32_t)q.Wo;
+            const int ox = (int)(m - row * q.Wo), b = (int)(row / (uint32_t)q.Ho), oy = (int)(row - (uint32_t)b * q.Ho);
+            float s[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {                       // same tap order as dw_fwd_kernel: bitwise the same z
+                const int iy = oy * q.stride - q.pad_t + t / 3, ix = ox * q.stride - q.pad_l + t % 3;
+                if ((unsigned)iy < (unsigned)q.Hi && (unsigned)ix < (unsigned)q.Wi) {
+                    float xv[V];
+                    ldv<V>(x + (((size_t)b * q.Hi + iy) * q.Wi + ix) * q.C + c, xv);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) s[k] += xv[k] * wv[t][k];
+                }
+            }
+            stv<V>(y + (size_t)m * q.C + c, s);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                s0[k] += (double)s[k];
+                s1[k] += (double)s[k] * (double)s[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        red[0][threadIdx.x][k] = s0[k];
+        red[1][threadIdx.x][k] = s1[k];
+    }
+    __syncthreads();
+    if (rl == 0 && c < q.C) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            double a = 0, b = 0;
+            for (int r = 0; r < RL; ++r) {
+                a += red[0][r * CW + cl][k];
+                b += red[1][r * CW + cl][k];
+            }
+            partial[((size_t)blockIdx.x * 2 + 0) * q.C + c + k] = a;
+            partial[((size_t)blockIdx.x * 2 + 1) * q.C + c + k] = b;
+        }
+    }
+}
+
+// statistics from `chunks` partials, then the apply pass
+static int bn_finish_apply(const float *z, long long M, int C, const double *partial, int chunks, const float *gamma, const float *beta, float eps, int act,
+                           float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean, float *moving_var, float momentum,
+                           const float *res, hipStream_t st) {
+    if (chunks > 1024)
+        hipLaunchKernelGGL(bn_stats_finish_kernel<4>, dim3(C), dim3(256), 0, st, partial, chunks, C, 1.0 / (double)M, eps, save_mean, save_invstd,
+                           moving_mean, moving_var, momentum);
+    else
+        hipLaunchKernelGGL(bn_stats_finish_kernel<1>, dim3((C + 3) / 4), dim3(256), 0, st, partial, chunks, C, 1.0 / (double)M, eps, save_mean, save_invstd,
+                           moving_mean, moving_var, momentum);
+    const size_t total = (size_t)M * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
+                           (const float *)save_invstd, gamma, beta, act, alpha, y, res);
+    else
+        hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, total, C, (const float *)save_mean,
+                           (const float *)save_invstd, gamma, beta, act, alpha, y, res);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+
+extern "C" int yk_gemm_bn_fwd_f32(int M, int N, int K, const float *X, int ldx, const float *W, int ldw, float *z, const float *gamma, const float *beta,
+                                  float eps, int act, float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean,
+                                  float *moving_var, float momentum, const float *res, void *stream) {
+    if (!X || !W || !z || !y || !gamma || !beta || !save_mean || !save_invstd || M <= 0 || N <= 0 || K <= 0) {
+        yk_set_error("yk_gemm_bn_fwd_f32: bad argument");
+        return YK_ERR_ARG;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    gemm_args g;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = N; g.transA = 0; g.transB = 1;
+    g.alpha = 1.f; g.beta = 0.f; g.A = X; g.B = W; g.C = z; g.ws = nullptr; g.stats = nullptr;
+    const int s = gemm_splits(M, N, K);
+    g.splitk = s;
+    const int mt = (M + 63) / 64;
+    int rpc = 0, cwl = 0;
+    const int chunks = s > 1 ? bn_chunking((size_t)M, N, &rpc, &cwl) : mt;
+    double *partial = (double *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * N + sizeof(float) * N);
+    if (!partial) return YK_ERR_NOMEM;
+    const dim3 grid(mt, (N + 63) / 64, s);
+    if (s > 1) {
+        g.ws = (float *)yk_scratch(dev, stream, 14, sizeof(float) * (size_t)s * M * N);
+        if (!g.ws) return YK_ERR_NOMEM;
+        launch_gemm_v2<false, true>(g, grid, st);
+        hipLaunchKernelGGL(splitk_sum_stats_kernel, dim3(chunks, (N + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, (const float *)g.ws, s, (size_t)M, N, z, N,
+                           rpc, cwl, partial);
+    } else {
+        g.stats = partial;
+        launch_gemm_fwd_stats(g, grid, st);
+    }
+    return bn_finish_apply(z, M, N, partial, chunks, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res, st);
+}
+
+extern "C" int yk_dw3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                                   float *z, const float *gamma, const float *beta, float eps, int act, float alpha, float *y, float *save_mean,
+                                   float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream) {
+    if (!x || !w || !z || !y || !gamma || !beta || !save_mean || !save_invstd || B <= 0 || C <= 0) {
+        yk_set_error("yk_dw3x3_bn_fwd_f32: bad argument");
+        return YK_ERR_ARG;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
+    const long long M = (long long)B * Ho * Wo;
+    if (M >= (1ll << 31)) {
+        yk_set_error("yk_dw3x3_bn_fwd_f32: more than 2^31 output pixels");
+        return YK_ERR_ARG;
+    }
+    const int V = C % 4 == 0 ? 4 : 1, CV = C / V;
+    const int CW = std::min(CV, 256), RL = 256 / CW, groups = (CV + CW - 1) / CW;
+    // ~4 rows per thread (a thread's rows are a serial chain of load -> multiply-add -> store: 16 rows per thread measured 37-61 us per launch
+    // whatever the size, r6c44), at most 8192 chunks (past 1024 the wide finishing kernel folds them)
+    int chunks = (int)std::min<long long>(8192, (M + RL * 4 - 1) / (RL * 4));
+    const int rpc = (int)(((M + chunks - 1) / chunks + RL - 1) / RL * RL);
+    chunks = (int)((M + rpc - 1) / rpc);
+    double *partial = (double *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
+    if (!partial) return YK_ERR_NOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    if (V == 4) hipLaunchKernelGGL(dw_fwd_stats_kernel<4>, dim3(chunks, groups), dim3(256), 0, st, q, x, w, z, rpc, CW, RL, partial);
+    else hipLaunchKernelGGL(dw_fwd_stats_kernel<1>, dim3(chunks, groups), dim3(256), 0, st, q, x, w, z, rpc, CW, RL, partial);
+    return bn_finish_apply(z, M, C, partial, chunks, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res, st);
 }
 
 // bias add (+ optional column sum of the gradient for the bias) for the two biased output convs

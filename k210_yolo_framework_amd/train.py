@@ -219,6 +219,7 @@ class Trainer:
                 l = self.lay[op['layer']]
                 w = self.view(self.P, l.name + '/kernel')
                 z = self._new(self.B, ho, wo, co)
+                a = kk = None
                 if t == ns.OP_CONV:
                     ci, k = op['cin'], op['k']
                     if k == 1 and op['stride'] == 1:
@@ -227,28 +228,35 @@ class Trainer:
                         assert k == 3
                         a, kk = self._new(M, 9 * ci), 9 * ci
                         self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(a), self._s()), 'yk_im2col3x3_f32')
-                    self.gemm(0, 1, M, co, kk, a, kk, w, kk, z, co)                      # Z = X * W^T
-                else:
-                    self._ck(self.L.yk_dw3x3_fwd_f32(engine._ptr(x), engine._ptr(w), *self._geom(op), engine._ptr(z), self._s()),
-                             'yk_dw3x3_fwd_f32')
                 if l.bn_name:
+                    # convolution + batch statistics + apply in one library call: the producer of z leaves the partial sums of the
+                    # statistics (yk_gemm_bn_fwd_f32 / yk_dw3x3_bn_fwd_f32), z is not read a second time for them
                     y = self._new(self.B, ho, wo, co)
                     mean, invstd = self._new(co), self._new(co)
                     fa = fused_add.get(i)
                     res = T[fa[1]] if fa is not None else None       # keras Add()([res, this output]) folded into the apply pass
-                    self._ck(self.L.yk_bn_train_fwd_res_f32(
-                        engine._ptr(z), C.c_longlong(M), C.c_int(co), engine._ptr(self.view(self.P, l.bn_name + '/gamma')),
-                        engine._ptr(self.view(self.P, l.bn_name + '/beta')), C.c_float(ns.BN_EPS), C.c_int(op['act']),
-                        C.c_float(op['alpha']), engine._ptr(y), engine._ptr(mean), engine._ptr(invstd),
-                        engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
-                        C.c_float(BN_MOMENTUM_V2 if self.spec.name == 'yolo_mobilev2' and not _is_darknet_conv(l.name) else BN_MOMENTUM),
-                        engine._ptr(res) if res is not None else None, self._s()), 'yk_bn_train_fwd_res_f32')
+                    bn = (engine._ptr(z), engine._ptr(self.view(self.P, l.bn_name + '/gamma')),
+                          engine._ptr(self.view(self.P, l.bn_name + '/beta')), C.c_float(ns.BN_EPS), C.c_int(op['act']),
+                          C.c_float(op['alpha']), engine._ptr(y), engine._ptr(mean), engine._ptr(invstd),
+                          engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
+                          C.c_float(BN_MOMENTUM_V2 if self.spec.name == 'yolo_mobilev2' and not _is_darknet_conv(l.name) else BN_MOMENTUM),
+                          engine._ptr(res) if res is not None else None, self._s())
+                    if t == ns.OP_CONV:
+                        self._ck(self.L.yk_gemm_bn_fwd_f32(C.c_int(M), C.c_int(co), C.c_int(kk), engine._ptr(a), C.c_int(kk), engine._ptr(w),
+                                                           C.c_int(kk), *bn), 'yk_gemm_bn_fwd_f32')           # Z = X * W^T
+                    else:
+                        self._ck(self.L.yk_dw3x3_bn_fwd_f32(engine._ptr(x), engine._ptr(w), *self._geom(op), *bn), 'yk_dw3x3_bn_fwd_f32')
                     S[i] = dict(z=z, mean=mean, invstd=invstd)
                     if fa is not None:                               # y IS the Add's output; the conv's own output tensor is never needed again
                         T[self.spec.ops[fa[0]]['out']] = y
                         done.add(fa[0])
                 else:
                     assert op['act'] == ns.ACT_NONE
+                    if t == ns.OP_CONV:
+                        self.gemm(0, 1, M, co, kk, a, kk, w, kk, z, co)                  # Z = X * W^T
+                    else:
+                        self._ck(self.L.yk_dw3x3_fwd_f32(engine._ptr(x), engine._ptr(w), *self._geom(op), engine._ptr(z), self._s()),
+                                 'yk_dw3x3_fwd_f32')
                     if l.use_bias:
                         self._ck(self.L.yk_bias_add_f32(engine._ptr(z), C.c_longlong(M), C.c_int(co),
                                                         engine._ptr(self.view(self.P, l.name + '/bias')), self._s()), 'yk_bias_add_f32')

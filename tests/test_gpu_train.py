@@ -150,6 +150,77 @@ def test_batchnorm_training_forward_backward(act, alpha, M, Cc):
         assert np.abs(got_dz - zt.grad.numpy())[safe].max() <= 5e-3 * np.abs(zt.grad.numpy()).max()
 
 
+@pytest.mark.parametrize('M,N,K,res', [(300, 75, 96, False),        # unsplit, ragged tile edges, scalar loads (K % 4 == 0 but N odd)
+                                       (4480, 96, 576, True),        # 14x20 at 16 images: K split, the slice-adding pass leaves the partials
+                                       (1120, 320, 960, False),      # 7x10: split
+                                       (40000, 24, 16, True),        # unsplit, 625 row tiles, one ragged column tile
+                                       (70000, 16, 27, False)])      # K % 4 != 0: the unvectorised loader; > 1024 partials: the wide finish
+def test_conv_bn_forward_in_one_call_equals_the_separate_calls(M, N, K, res):
+    """yk_gemm_bn_fwd_f32 = yk_gemm_f32 + yk_bn_train_fwd_res_f32 with the statistics' partial sums left by the producer of z: z bitwise the
+    same, mean / invstd / moving statistics / y within 1e-6 relative (the double sums are added in another order)."""
+    engine, L = _lib()
+    rng = np.random.default_rng(M + N)
+    X = (rng.normal(size=(M, K)) + 0.3).astype(np.float32)
+    W = rng.normal(size=(N, K)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 2, N).astype(np.float32), rng.normal(size=N).astype(np.float32)
+    r = rng.normal(size=(M, N)).astype(np.float32) if res else None
+    xd, wd, gd, bd = _cu(X), _cu(W), _cu(gamma), _cu(beta)
+    rd = _cu(r) if res else None
+    outs = []
+    for fused in (False, True):
+        z, y = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+        sm, si = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+        mm, mv = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda')
+        bn = (engine._ptr(gd), engine._ptr(bd), C.c_float(1e-3), ns.ACT_RELU6, C.c_float(6.0), engine._ptr(y), engine._ptr(sm), engine._ptr(si),
+              engine._ptr(mm), engine._ptr(mv), C.c_float(0.99), engine._ptr(rd) if res else None, _st())
+        if fused:
+            assert L.yk_gemm_bn_fwd_f32(M, N, K, engine._ptr(xd), K, engine._ptr(wd), K, engine._ptr(z), *bn) == 0, L.yk_last_error()
+        else:
+            assert L.yk_gemm_f32(0, 1, M, N, K, C.c_float(1), engine._ptr(xd), K, engine._ptr(wd), K, C.c_float(0), engine._ptr(z), N, _st()) == 0
+            assert L.yk_bn_train_fwd_res_f32(engine._ptr(z), C.c_longlong(M), N, *bn) == 0
+        outs.append([t.cpu().numpy() for t in (z, y, sm, si, mm, mv)])
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    for u, v in zip(a[2:], b[2:]):
+        _close(v, u, 1e-6)
+    assert np.abs(a[1] - b[1]).max() <= 1e-5 * np.abs(a[1]).max()
+    zz = X.astype(np.float64) @ W.astype(np.float64).T
+    _close(b[2], zz.mean(0), 1e-5)
+    _close(b[3], 1 / np.sqrt(zz.var(0) + 1e-3), 1e-5)
+
+
+@pytest.mark.parametrize('stride,Cc', [(1, 72), (2, 24), (1, 130)])
+def test_depthwise_bn_forward_in_one_call_equals_the_separate_calls(stride, Cc):
+    engine, L = _lib()
+    rng = np.random.default_rng(20 + stride)
+    B, Hi, Wi = 5, 29, 38
+    Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+    M = B * Ho * Wo
+    x = rng.normal(size=(B, Hi, Wi, Cc)).astype(np.float32)
+    w = rng.normal(size=(9, Cc)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 2, Cc).astype(np.float32), rng.normal(size=Cc).astype(np.float32)
+    geom = [C.c_int(v) for v in (B, Hi, Wi, Cc, Ho, Wo, stride, 1, 1)]
+    xd, wd, gd, bd = _cu(x), _cu(w), _cu(gamma), _cu(beta)
+    outs = []
+    for fused in (False, True):
+        z, y = torch.empty(M, Cc, device='cuda'), torch.empty(M, Cc, device='cuda')
+        sm, si = torch.empty(Cc, device='cuda'), torch.empty(Cc, device='cuda')
+        mm, mv = torch.zeros(Cc, device='cuda'), torch.ones(Cc, device='cuda')
+        bn = (engine._ptr(gd), engine._ptr(bd), C.c_float(1e-3), ns.ACT_RELU, C.c_float(0.0), engine._ptr(y), engine._ptr(sm), engine._ptr(si),
+              engine._ptr(mm), engine._ptr(mv), C.c_float(0.999), None, _st())
+        if fused:
+            assert L.yk_dw3x3_bn_fwd_f32(engine._ptr(xd), engine._ptr(wd), *geom, engine._ptr(z), *bn) == 0, L.yk_last_error()
+        else:
+            assert L.yk_dw3x3_fwd_f32(engine._ptr(xd), engine._ptr(wd), *geom, engine._ptr(z), _st()) == 0
+            assert L.yk_bn_train_fwd_res_f32(engine._ptr(z), C.c_longlong(M), Cc, *bn) == 0
+        outs.append([t.cpu().numpy() for t in (z, y, sm, si, mm, mv)])
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    for u, v in zip(a[2:], b[2:]):
+        _close(v, u, 1e-6)
+    assert np.abs(a[1] - b[1]).max() <= 1e-5 * np.abs(a[1]).max()
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_maxpool_upsample_bias_colsum_axpy(stride):
     engine, L = _lib()
