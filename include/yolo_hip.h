@@ -306,6 +306,11 @@ int yk_yolo_loss(const yk_loss_cfg_t *cfg, const float *d_y_true, const float *d
  *   data gradient dX = dY * W, weight gradient dW = dY^T * X (tf Conv2DBackpropInput / ...Filter). */
 int yk_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb,
                 float beta, float *C, int ldc, void *stream);
+/* `count` independent GEMMs of one layout in as few launches as possible (the weight gradients of a whole backward pass): the problems'
+ * tiles share one grid and the K slices are sized for the group (results reproducible run to run; equal to yk_gemm_f32's within fp32
+ * summation-order differences). */
+int yk_gemm_f32_grouped(int count, int transA, int transB, const int *M, const int *N, const int *K, float alpha, const float *const *A,
+                        const int *lda, const float *const *B, const int *ldb, float beta, float *const *C, const int *ldc, void *stream);
 /* 3x3 Conv2D through GEMM: col [B*Ho*Wo][9*C], k = (ky*3+kx)*C + c; col2im is the adjoint (sums overlaps). */
 int yk_im2col3x3_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
                      float *col, void *stream);
@@ -318,6 +323,9 @@ int yk_dw3x3_bwd_data_f32(const float *dy, const float *w, int B, int Hi, int Wi
                           int pad_t, int pad_l, float *dx, void *stream);
 int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride,
                             int pad_t, int pad_l, float *dw, void *stream);
+/* the depthwise weight gradients of `count` layers in two launches; geom: 9 ints per problem (B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l);
+ * every problem computed exactly as by yk_dw3x3_bwd_weight_f32 (bitwise the same). */
+int yk_dw3x3_bwd_weight_grouped_f32(int count, const float *const *x, const float *const *dy, const int *geom, float *const *dw, void *stream);
 /* BatchNormalization(training=True) fused with the activation that follows it (act: YK_ACT_*).
  * fwd: batch mean / biased variance over M, y = act(gamma*(z-mean)*invstd + beta); saves mean and invstd and,
  *      when moving_mean/moving_var are given, updates them with `momentum` (Keras: 0.99).

@@ -16,17 +16,23 @@
 
 // STATS (forward of a conv followed by BatchNormalization, unsplit K): the epilogue also leaves the column sums of its 64 rows of C -
 // sum and sum of squares in double, partial[(m tile * 2 + {0,1}) * N + n] - so the batch statistics need no second pass over C.
-template <bool TA, bool TB, bool VEC, bool STATS = false>
-__global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
+template <bool TA, bool TB>
+struct gemm_v2_lds {
+    static constexpr int BK = 32, LDM = 34, LDK = 80;
+    static constexpr int SA = TA ? BK * LDK : 64 * LDM, SB = TB ? 64 * LDM : BK * LDK;      // floats per operand tile
+    static constexpr int FLOATS = 2 * (SA + SB);
+};
+// one 64x64 tile (tile indices bx, by; K slice bz) of the problem g; lds: gemm_v2_lds<TA, TB>::FLOATS floats, 16-byte aligned
+template <bool TA, bool TB, bool VEC, bool STATS>
+__device__ __forceinline__ void gemm_f32_v2_tile(const gemm_args g, const int bx, const int by, const int bz, float *__restrict__ lds) {   // g BY VALUE: a reference to the kernel's argument struct put it on the stack (scratch loads in the k loop)
     constexpr int BK = 32, LDM = 34, LDK = 80;
-    constexpr int SA = TA ? BK * LDK : 64 * LDM, SB = TB ? 64 * LDM : BK * LDK;      // floats per operand tile
-    __shared__ __attribute__((aligned(16))) float lds[2 * (SA + SB)];
+    constexpr int SA = gemm_v2_lds<TA, TB>::SA, SB = gemm_v2_lds<TA, TB>::SB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int m0 = bx * 64, n0 = by * 64;
     const int nk = (g.K + BK - 1) / BK;
     const int per = (nk + g.splitk - 1) / g.splitk;
-    const int kb = blockIdx.z * per, ke = min(nk, kb + per);
+    const int kb = bz * per, ke = min(nk, kb + per);
     floatx4t acc[2][2];                                      // [n tile][m tile]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
     }
     // D layout: row = (lane>>4)*4 + r -> n, col = lane&15 -> m
     const bool slab = g.splitk > 1;
-    float *base = slab ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+    float *base = slab ? g.ws + (size_t)bz * g.M * g.N : g.C;
     const int ld = slab ? g.N : g.ldc;
     const bool vec = ((ld & 3) == 0) && ((g.N & 3) == 0) && ((((uintptr_t)base) & 15) == 0);
 #pragma unroll
@@ -176,9 +182,37 @@ __global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
         if (tid < 128) {
             const int jj = tid >> 6;
             const double t = ((red[(jj * 4 + 0) * 64 + n] + red[(jj * 4 + 1) * 64 + n]) + red[(jj * 4 + 2) * 64 + n]) + red[(jj * 4 + 3) * 64 + n];
-            if (n0 + n < g.N) g.stats[((size_t)blockIdx.x * 2 + jj) * g.N + n0 + n] = t;
+            if (n0 + n < g.N) g.stats[((size_t)bx * 2 + jj) * g.N + n0 + n] = t;
         }
     }
+}
+
+template <bool TA, bool TB, bool VEC, bool STATS = false>
+__global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_v2_lds<TA, TB>::FLOATS];
+    gemm_f32_v2_tile<TA, TB, VEC, STATS>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// GROUPED launch (round 6): up to YK_GROUP_MAX independent problems of one layout in ONE launch - the weight gradients of a whole backward
+// pass (37 GEMMs of 1-30 tiles each, every one split over K to reach ~1000 workgroups, every one followed by its slice-adding launch).  The
+// problems ride in the kernel arguments; workgroup w belongs to the problem i with first[i] <= w < first[i + 1].  Same tile code; the host sizes
+// the K slices for the group as a whole (yk_gemm_f32_grouped).
+#define YK_GROUP_MAX 36
+struct gemm_group {
+    int count;
+    int first[YK_GROUP_MAX + 1];
+    gemm_args p[YK_GROUP_MAX];
+};
+static_assert(sizeof(gemm_group) <= 4096, "the group rides in the kernel arguments");
+template <bool TA, bool TB, bool VEC>
+__global__ void __launch_bounds__(256) gemm_f32_grouped_kernel(const gemm_group G) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_v2_lds<TA, TB>::FLOATS];
+    int i = 0;
+    while (i + 1 < G.count && (int)blockIdx.x >= G.first[i + 1]) ++i;
+    const gemm_args g = G.p[i];
+    const int local = (int)blockIdx.x - G.first[i], tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+    const int bx = local % tm, r = local / tm;
+    gemm_f32_v2_tile<TA, TB, VEC, false>(g, bx, r % tn, r / tn, lds);
 }
 
 template <bool TA, bool TB>

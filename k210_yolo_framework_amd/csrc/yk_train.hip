@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <vector>
 
 typedef float floatx4t __attribute__((ext_vector_type(4)));
 
@@ -200,6 +201,139 @@ extern "C" int yk_gemm_f32(int transA, int transB, int M, int N, int K, float al
         else
             hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, M, N, alpha, beta,
                                C, ldc);
+    }
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+
+// ---- grouped GEMMs (yk_gemm_f32.h): the K-slice sums of all problems of a group in one launch too
+struct sum_item {
+    const float *ws;
+    float *c;
+    int splits, M, N, ldc, first, wide;      // wide: 16 lanes per output (splits >= 16, small result), as splitk_sum16_kernel
+};
+struct sum_group {
+    int count;
+    float alpha, beta;
+    sum_item p[YK_GROUP_MAX];
+};
+__global__ void __launch_bounds__(256) splitk_sum_grouped_kernel(const sum_group S) {
+    __shared__ float red[16][17];
+    int i = 0;
+    while (i + 1 < S.count && (int)blockIdx.x >= S.p[i + 1].first) ++i;
+    const sum_item &q = S.p[i];
+    const int local = (int)blockIdx.x - q.first;
+    const size_t tot = (size_t)q.M * q.N;
+    if (!q.wide) {                                           // = splitk_sum_kernel
+        const size_t e = (size_t)local * 256 + threadIdx.x;
+        if (e >= tot) return;
+        float s = 0.f;
+        for (int z = 0; z < q.splits; ++z) s += q.ws[(size_t)z * tot + e];
+        const size_t r = e / q.N, c = e - r * q.N;
+        float *o = q.c + r * q.ldc + c;
+        *o = S.alpha * s + (S.beta != 0.f ? S.beta * *o : 0.f);
+        return;
+    }
+    const int zl = threadIdx.x >> 4, il = threadIdx.x & 15;  // = splitk_sum16_kernel
+    const size_t e = (size_t)local * 16 + il;
+    float s = 0.f;
+    if (e < tot) {
+#pragma unroll 8
+        for (int z = zl; z < q.splits; z += 16) s += q.ws[(size_t)z * tot + e];
+    }
+    red[zl][il] = s;
+    __syncthreads();
+    if (zl == 0 && e < tot) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][il];
+        const size_t r = e / q.N, c = e - r * q.N;
+        float *o = q.c + r * q.ldc + c;
+        *o = S.alpha * t + (S.beta != 0.f ? S.beta * *o : 0.f);
+    }
+}
+
+// `count` independent GEMMs of ONE layout (transA, transB) and one (alpha, beta), YK_GROUP_MAX problems per launch: the tile code of
+// yk_gemm_f32 with K slices sized for the group (fixed order of additions: reproducible run to run, not bit-equal to the separate call
+// when the slice counts differ).  Problems whose shapes or addresses rule out 16-byte loads go through yk_gemm_f32 one by one.
+extern "C" int yk_gemm_f32_grouped(int count, int transA, int transB, const int *M, const int *N, const int *K, float alpha, const float *const *A,
+                                   const int *lda, const float *const *B, const int *ldb, float beta, float *const *C, const int *ldc, void *stream) {
+    if (count < 0 || (count && (!M || !N || !K || !A || !lda || !B || !ldb || !C || !ldc))) {
+        yk_set_error("yk_gemm_f32_grouped: bad argument");
+        return YK_ERR_ARG;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> grouped;
+    std::vector<int> splits(count, 1);
+    size_t ws_floats = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!A[i] || !B[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || K[i] <= 0) {
+            yk_set_error("yk_gemm_f32_grouped: bad problem %d", i);
+            return YK_ERR_ARG;
+        }
+        const bool va = transA ? (M[i] % 4 == 0) : (K[i] % 4 == 0), vb = transB ? (K[i] % 4 == 0) : (N[i] % 4 == 0);
+        const bool vec = va && vb && lda[i] % 4 == 0 && ldb[i] % 4 == 0 && (((uintptr_t)A[i] | (uintptr_t)B[i]) & 15) == 0;
+        if (!vec || (transA && transB)) {
+            const int rc = yk_gemm_f32(transA, transB, M[i], N[i], K[i], alpha, A[i], lda[i], B[i], ldb[i], beta, C[i], ldc[i], stream);
+            if (rc != YK_OK) return rc;
+            continue;
+        }
+        grouped.push_back(i);
+    }
+    if (grouped.empty()) return YK_OK;
+    // K slices: alone, a problem is split until ITS tiles fill the chip (~1000 workgroups: 16 MB of slabs each, 0.56 GB written and read
+    // again for the 35 weight gradients of configs[3]: r6c54).  Together the tiles of all problems fill it: slices of ~T k-steps such that the
+    // group has ~8192 workgroups, never more slices than the problem would take alone.
+    {
+        double units = 0;
+        for (int i : grouped) units += (double)((M[i] + 63) / 64) * ((N[i] + 63) / 64) * ((K[i] + 31) / 32);
+        const double T = std::max(8.0, units / 8192.0);
+        for (int i : grouped) {
+            const int nk = (K[i] + 31) / 32;
+            splits[i] = std::max(1, std::min(gemm_splits(M[i], N[i], K[i]), (int)((nk + T - 1) / T)));
+            if (splits[i] > 1) ws_floats += ((size_t)splits[i] * M[i] * N[i] + 3) / 4 * 4;
+        }
+    }
+    float *ws = nullptr;
+    if (ws_floats) {
+        ws = (float *)yk_scratch(dev, stream, 22, sizeof(float) * ws_floats);
+        if (!ws) return YK_ERR_NOMEM;
+    }
+    size_t ws_off = 0;
+    for (size_t g0 = 0; g0 < grouped.size(); g0 += YK_GROUP_MAX) {
+        const int n = (int)std::min<size_t>(YK_GROUP_MAX, grouped.size() - g0);
+        gemm_group G;
+        sum_group S;
+        G.count = n;
+        S.count = 0;
+        S.alpha = alpha;
+        S.beta = beta;
+        int wg = 0, swg = 0;
+        for (int j = 0; j < n; ++j) {
+            const int i = grouped[g0 + j];
+            gemm_args &g = G.p[j];
+            g.M = M[i]; g.N = N[i]; g.K = K[i]; g.lda = lda[i]; g.ldb = ldb[i]; g.ldc = ldc[i]; g.transA = transA; g.transB = transB;
+            g.alpha = alpha; g.beta = beta; g.A = A[i]; g.B = B[i]; g.C = C[i]; g.stats = nullptr; g.ws = nullptr;
+            g.splitk = splits[i];
+            if (splits[i] > 1) {
+                g.ws = ws + ws_off;
+                ws_off += ((size_t)splits[i] * M[i] * N[i] + 3) / 4 * 4;
+                sum_item &q = S.p[S.count++];
+                const size_t tot = (size_t)M[i] * N[i];
+                q.ws = g.ws; q.c = C[i]; q.splits = splits[i]; q.M = M[i]; q.N = N[i]; q.ldc = ldc[i]; q.first = swg;
+                q.wide = splits[i] >= 16 && tot <= 65536;
+                swg += (int)(q.wide ? (tot + 15) / 16 : (tot + 255) / 256);
+            }
+            G.first[j] = wg;
+            wg += ((M[i] + 63) / 64) * ((N[i] + 63) / 64) * splits[i];
+        }
+        G.first[n] = wg;
+        if (!transA && transB) hipLaunchKernelGGL((gemm_f32_grouped_kernel<false, true, true>), dim3(wg), dim3(256), 0, st, G);
+        else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_grouped_kernel<false, false, true>), dim3(wg), dim3(256), 0, st, G);
+        else hipLaunchKernelGGL((gemm_f32_grouped_kernel<true, false, true>), dim3(wg), dim3(256), 0, st, G);
+        if (S.count) hipLaunchKernelGGL(splitk_sum_grouped_kernel, dim3(swg), dim3(256), 0, st, S);
     }
     YK_HIP(hipGetLastError());
     return YK_OK;
@@ -481,14 +615,14 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(const float *__restr
 // channel groups); partial[chunk][9][C] is folded by colsum_finish_kernel.
 // A thread sweeps ONE segment of an image row of one channel (shift register over x).  `segs` segments per row: whole rows gave the
 // 112x160x32 layer 224 workgroups of serial 160-pixel sweeps (73 MB at 1 TB/s); four segments per row are 896 workgroups.
-__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
-                                                            float *__restrict__ partial, int rows_per_chunk, int cw_log2, int segs, int wseg) {
-    __shared__ float red[9][256];
+__device__ __forceinline__ void dw_bwd_weight_body(const conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
+                                                   float *__restrict__ partial, const int rows_per_chunk, const int cw_log2, const int segs, const int wseg,
+                                                   const int bx, const int by, float (*red)[256]) {
     const int CW = 1 << cw_log2, RL = 256 >> cw_log2;
     const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_log2;
-    const int c = blockIdx.y * CW + cl;
+    const int c = by * CW + cl;
     const int rows = q.B * q.Ho * segs;                            // virtual rows: (image row, segment)
-    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    const int r0 = bx * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (c < q.C)
         for (int vr = r0 + rl; vr < r1; vr += RL) {
@@ -548,8 +682,46 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const f
         for (int t = 0; t < 9; ++t) {
             float a = 0.f;
             for (int k = 0; k < RL; ++k) a += red[t][k * CW + cl];
-            partial[((size_t)blockIdx.x * 9 + t) * q.C + c] = a;
+            partial[((size_t)bx * 9 + t) * q.C + c] = a;
         }
+}
+__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(conv_geom q, const float *__restrict__ x, const float *__restrict__ dy,
+                                                            float *__restrict__ partial, int rows_per_chunk, int cw_log2, int segs, int wseg) {
+    __shared__ float red[9][256];
+    dw_bwd_weight_body(q, x, dy, partial, rows_per_chunk, cw_log2, segs, wseg, blockIdx.x, blockIdx.y, red);
+}
+// GROUPED (round 6): the depthwise weight gradients of a whole backward pass in one launch + one finishing launch (17 + 17 launches of
+// configs[3] become 2); the problems ride in the kernel arguments, each computed exactly as by the separate launches (bitwise the same).
+struct dww_item {
+    conv_geom q;
+    const float *x, *dy;
+    float *partial, *dw;
+    int rpc, cwl, segs, wseg, chunks, groups, first, ffirst;     // first / ffirst: first workgroup of the problem in the main / finishing launch
+};
+struct dww_group {
+    int count;
+    dww_item p[YK_GROUP_MAX];
+};
+static_assert(sizeof(dww_group) <= 4096, "the group rides in the kernel arguments");
+__global__ void __launch_bounds__(256) dw_bwd_weight_grouped_kernel(const dww_group G) {
+    __shared__ float red[9][256];
+    int i = 0;
+    while (i + 1 < G.count && (int)blockIdx.x >= G.p[i + 1].first) ++i;
+    const dww_item it = G.p[i];
+    const int local = (int)blockIdx.x - it.first;
+    dw_bwd_weight_body(it.q, it.x, it.dy, it.partial, it.rpc, it.cwl, it.segs, it.wseg, local % it.chunks, local / it.chunks, red);
+}
+__global__ void __launch_bounds__(256) colsum_finish_grouped_kernel(const dww_group G) {
+    int i = 0;
+    while (i + 1 < G.count && (int)blockIdx.x >= G.p[i + 1].ffirst) ++i;
+    const dww_item it = G.p[i];
+    const int n = 9 * it.q.C;
+    const int o = ((int)blockIdx.x - it.ffirst) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= n) return;
+    float s = 0.f;
+    for (int k = lane; k < it.chunks; k += 64) s += it.partial[(size_t)k * n + o];
+    s = wave_sum(s);
+    if (lane == 0) it.dw[o] = s;
 }
 
 static int lane_split(int C) { return C <= 16 ? 4 : (C <= 32 ? 5 : 6); }      // log2 of the channel lanes per block
@@ -579,25 +751,85 @@ extern "C" int yk_dw3x3_bwd_data_f32(const float *dy, const float *w, int B, int
     YK_HIP(hipGetLastError());
     return YK_OK;
 }
+struct dww_plan {
+    int cwl, groups, segs, wseg, rpc, chunks;
+};
+static dww_plan dww_planning(int B, int C, int Ho, int Wo) {
+    dww_plan p;
+    p.cwl = lane_split(C);
+    const int RL = 256 >> p.cwl;
+    p.groups = (C + (1 << p.cwl) - 1) >> p.cwl;
+    // segments per image row: enough (row, segment) units for ~1024 workgroups of RL units each, at least 8 pixels per segment
+    int segs = (1024 * RL + B * Ho * p.groups - 1) / (B * Ho * p.groups);
+    segs = std::max(1, std::min(segs, std::min(8, Wo / 8)));
+    p.wseg = (Wo + segs - 1) / segs;
+    p.segs = (Wo + p.wseg - 1) / p.wseg;
+    const int rows = B * Ho * p.segs;
+    p.rpc = ((rows + 2047) / 2048 + RL - 1) / RL * RL;        // whole row-lane rounds per chunk, at most ~2048 chunks
+    p.chunks = (rows + p.rpc - 1) / p.rpc;
+    return p;
+}
 extern "C" int yk_dw3x3_bwd_weight_f32(const float *x, const float *dy, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride,
                                        int pad_t, int pad_l, float *dw, void *stream) {
     conv_geom q = {B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l};
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
-    const int cwl = lane_split(C), RL = 256 >> cwl, groups = (C + (1 << cwl) - 1) >> cwl;
-    // segments per image row: enough (row, segment) units for ~1024 workgroups of RL units each, at least 8 pixels per segment
-    int segs = (1024 * RL + B * Ho * groups - 1) / (B * Ho * groups);
-    segs = std::max(1, std::min(segs, std::min(8, Wo / 8)));
-    const int wseg = (Wo + segs - 1) / segs;
-    segs = (Wo + wseg - 1) / wseg;
-    const int rows = B * Ho * segs;
-    int rpc = ((rows + 2047) / 2048 + RL - 1) / RL * RL;        // whole row-lane rounds per chunk, at most ~2048 chunks
-    const int chunks = (rows + rpc - 1) / rpc;
-    float *partial = (float *)yk_scratch(dev, stream, 12, sizeof(float) * (size_t)chunks * 9 * C);
+    const dww_plan p = dww_planning(B, C, Ho, Wo);
+    float *partial = (float *)yk_scratch(dev, stream, 12, sizeof(float) * (size_t)p.chunks * 9 * C);
     if (!partial) return YK_ERR_NOMEM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, groups), dim3(256), 0, st, q, x, dy, partial, rpc, cwl, segs, wseg);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((9 * C + 3) / 4), dim3(256), 0, st, partial, chunks, 9 * C, dw, 1.f);
+    hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(p.chunks, p.groups), dim3(256), 0, st, q, x, dy, partial, p.rpc, p.cwl, p.segs, p.wseg);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((9 * C + 3) / 4), dim3(256), 0, st, partial, p.chunks, 9 * C, dw, 1.f);
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+// geom: 9 ints per problem (B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l), as the arguments of yk_dw3x3_bwd_weight_f32
+extern "C" int yk_dw3x3_bwd_weight_grouped_f32(int count, const float *const *x, const float *const *dy, const int *geom, float *const *dw, void *stream) {
+    if (count < 0 || (count && (!x || !dy || !geom || !dw))) {
+        yk_set_error("yk_dw3x3_bwd_weight_grouped_f32: bad argument");
+        return YK_ERR_ARG;
+    }
+    if (!count) return YK_OK;
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<dww_plan> plans(count);
+    size_t floats = 0;
+    for (int i = 0; i < count; ++i) {
+        const int *g = geom + 9 * i;
+        if (!x[i] || !dy[i] || !dw[i] || g[0] <= 0 || g[3] <= 0) {
+            yk_set_error("yk_dw3x3_bwd_weight_grouped_f32: bad problem %d", i);
+            return YK_ERR_ARG;
+        }
+        plans[i] = dww_planning(g[0], g[3], g[4], g[5]);
+        floats += (size_t)plans[i].chunks * 9 * g[3];
+    }
+    float *partial = (float *)yk_scratch(dev, stream, 23, sizeof(float) * floats);
+    if (!partial) return YK_ERR_NOMEM;
+    size_t off = 0;
+    for (int g0 = 0; g0 < count; g0 += YK_GROUP_MAX) {
+        const int n = std::min(YK_GROUP_MAX, count - g0);
+        dww_group G;
+        G.count = n;
+        int wg = 0, fwg = 0;
+        for (int j = 0; j < n; ++j) {
+            const int i = g0 + j;
+            const int *g = geom + 9 * i;
+            dww_item &it = G.p[j];
+            it.q = conv_geom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8]};
+            it.x = x[i]; it.dy = dy[i]; it.dw = dw[i];
+            it.partial = partial + off;
+            off += (size_t)plans[i].chunks * 9 * g[3];
+            it.rpc = plans[i].rpc; it.cwl = plans[i].cwl; it.segs = plans[i].segs; it.wseg = plans[i].wseg;
+            it.chunks = plans[i].chunks; it.groups = plans[i].groups;
+            it.first = wg;
+            it.ffirst = fwg;
+            wg += it.chunks * it.groups;
+            fwg += (9 * g[3] + 3) / 4;
+        }
+        hipLaunchKernelGGL(dw_bwd_weight_grouped_kernel, dim3(wg), dim3(256), 0, st, G);
+        hipLaunchKernelGGL(colsum_finish_grouped_kernel, dim3(fwg), dim3(256), 0, st, G);
+    }
     YK_HIP(hipGetLastError());
     return YK_OK;
 }

@@ -88,6 +88,11 @@ class Trainer:
         import os as _os
         self.wgrad_chunks = max(0, int(_os.environ.get('YK_TRAIN_WSTREAM', '0') or 0))
         self.wgrad_stream = self.wgrad_chunks > 0
+        # ... what does pay (round 6): the 1x1 convs' weight gradients are independent GEMMs of 1-30 tiles each; collected during the backward
+        # walk and issued as ONE grouped launch at its end (yk_gemm_f32_grouped: bitwise the same results), their tiles fill the chip
+        # together - 35 GEMMs + 35 slice-adding launches become 2, the depthwise weight gradients (17 + 17) 2 more.  YK_TRAIN_GROUP_WGRAD=0: one launch
+        # per layer as before.
+        self.group_wgrad = (_os.environ.get('YK_TRAIN_GROUP_WGRAD', '1') or '1') != '0' and not self.wgrad_stream
         self._ws = None
         self._l2_seg = None
         self._fa = None
@@ -302,6 +307,8 @@ class Trainer:
         if ws is not None:
             ws.wait_stream(main)                                    # G is zero, the forward tape is complete
 
+        grouped = []                                                # (dz, x, gw, co, ci, M) of the 1x1 convs: one grouped launch at the end
+        grouped_dw = []                                             # (x, dz, gw, geometry) of the depthwise convs: likewise
         pending = []                                                # deferred weight-gradient launches of the current chunk
         n_conv = sum(1 for o in self.spec.ops if o['type'] in (ns.OP_CONV, ns.OP_DWCONV))
         per_chunk = max(1, -(-n_conv // max(1, self.wgrad_chunks)))
@@ -372,7 +379,10 @@ class Trainer:
                 if t == ns.OP_CONV:
                     k = op['k']
                     if k == 1 and op['stride'] == 1:
-                        on_side(lambda dz=dz, x=x, gw=gw, co=co, ci=ci, M=M: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
+                        if self.group_wgrad:
+                            grouped.append((dz, x, gw, co, ci, M))                       # dW = dZ^T * X, with all the others below
+                        else:
+                            on_side(lambda dz=dz, x=x, gw=gw, co=co, ci=ci, M=M: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
                         if need_dx:
                             dx = self._new(self.B, hi, wi, ci)
                             self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)           # dX = dZ * W
@@ -391,8 +401,11 @@ class Trainer:
                         del col
                 else:
                     geom = self._geom(op)
-                    on_side(lambda x=x, dz=dz, gw=gw, geom=geom: self._ck(self.L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dz), *geom, engine._ptr(gw),
-                                                                                                          self._s()), 'yk_dw3x3_bwd_weight_f32'), dz)
+                    if self.group_wgrad:
+                        grouped_dw.append((x, dz, gw, [g.value for g in geom]))
+                    else:
+                        on_side(lambda x=x, dz=dz, gw=gw, geom=geom: self._ck(self.L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dz), *geom, engine._ptr(gw),
+                                                                                                              self._s()), 'yk_dw3x3_bwd_weight_f32'), dz)
                     if need_dx:
                         dx = self._new(self.B, hi, wi, ci)
                         self._ck(self.L.yk_dw3x3_bwd_data_f32(engine._ptr(dz), engine._ptr(w), *self._geom(op), engine._ptr(dx), self._s()),
@@ -432,6 +445,21 @@ class Trainer:
                 share = a_ != b_ and lone and fresh and first not in D and second not in D and all(j < pf for j in others) and second != 0
                 acc(second, dy, share)
                 acc(first, dy, True)
+        if grouped:
+            n = len(grouped)
+            ia = lambda v: (C.c_int * n)(*v)
+            pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            self._ck(self.L.yk_gemm_f32_grouped(C.c_int(n), C.c_int(1), C.c_int(0), ia([g[3] for g in grouped]), ia([g[4] for g in grouped]),
+                                                ia([g[5] for g in grouped]), C.c_float(1.0), pa([g[0] for g in grouped]), ia([g[3] for g in grouped]),
+                                                pa([g[1] for g in grouped]), ia([g[4] for g in grouped]), C.c_float(0.0), pa([g[2] for g in grouped]),
+                                                ia([g[4] for g in grouped]), self._s()), 'yk_gemm_f32_grouped')
+        if grouped_dw:
+            n = len(grouped_dw)
+            pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            geo = (C.c_int * (9 * n))(*[v for g in grouped_dw for v in g[3]])
+            self._ck(self.L.yk_dw3x3_bwd_weight_grouped_f32(C.c_int(n), pa([g[0] for g in grouped_dw]), pa([g[1] for g in grouped_dw]), geo,
+                                                            pa([g[2] for g in grouped_dw]), self._s()), 'yk_dw3x3_bwd_weight_grouped_f32')
+        del grouped, grouped_dw
         flush()
         if ws is not None:
             main.wait_stream(ws)                                    # every weight gradient is in G

@@ -52,6 +52,49 @@ def test_gemm_all_layouts_and_split_k(tA, tB, M, N, K):
     _close(c.cpu().numpy(), ref, 2e-5)
 
 
+@pytest.mark.parametrize('tA,tB', [(1, 0), (0, 1), (0, 0)])
+def test_grouped_gemms_equal_the_separate_calls(tA, tB):
+    """yk_gemm_f32_grouped: many independent problems in one grid (+ one launch for all the K-slice sums), K slices sized for the group: equal to
+    the separate calls within 2e-5 of the result's magnitude, and bitwise reproducible call to call.  Shapes of the weight gradients of a
+    backward pass: one-tile results over 70 000 rows (512 slices, the 16-lane sum), mid-size ones (a few slices, the plain sum), unsplit ones,
+    a shape without 16-byte rows (falls back to its own launch), and more problems than one group holds."""
+    engine, L = _lib()
+    rng = np.random.default_rng(7 + tA * 2 + tB)
+    shapes = [(96, 16, 70000), (16, 96, 70000), (144, 24, 17920), (320, 960, 1120), (24, 144, 4480), (75, 128, 1120), (64, 64, 64), (130, 36, 300)]
+    shapes = shapes + [(8 + 4 * (i % 5), 12 + 4 * (i % 3), 2000 + 400 * i) for i in range(40)]       # 48 problems: two groups
+    if not tA:
+        shapes = [(k if k < 5000 else 4480, n, m) for (m, n, k) in shapes]                         # keep M*K moderate for the row-major A layouts
+    As, Bs, Cs, refs, C0s = [], [], [], [], []
+    for (M, N, K) in shapes:
+        A = rng.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+        Bm = rng.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+        C0 = rng.normal(size=(M, N)).astype(np.float32)
+        a, b, c = _cu(A), _cu(Bm), _cu(C0)
+        ref = c.clone()
+        assert L.yk_gemm_f32(tA, tB, M, N, K, C.c_float(0.5), engine._ptr(a), A.shape[1], engine._ptr(b), Bm.shape[1], C.c_float(2.0),
+                             engine._ptr(ref), N, _st()) == 0
+        As.append(a); Bs.append(b); Cs.append(c); refs.append(ref); C0s.append(c.clone())
+    n = len(shapes)
+    ia = lambda v: (C.c_int * n)(*v)
+    pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    assert L.yk_gemm_f32_grouped(n, tA, tB, ia([s[0] for s in shapes]), ia([s[1] for s in shapes]), ia([s[2] for s in shapes]), C.c_float(0.5), pa(As),
+                                 ia([a.shape[1] for a in As]), pa(Bs), ia([b.shape[1] for b in Bs]), C.c_float(2.0), pa(Cs), ia([s[1] for s in shapes]),
+                                 _st()) == 0, L.yk_last_error()
+    torch.cuda.synchronize()
+    for k, (c, r) in enumerate(zip(Cs, refs)):
+        _close(c.cpu().numpy(), r.cpu().numpy(), 2e-5)
+    first = [c.clone() for c in Cs]
+    for c, c0 in zip(Cs, C0s):                                   # (beta = 2 reads C: restore the inputs, run again, compare bit for bit)
+        c.copy_(c0)
+    assert L.yk_gemm_f32_grouped(n, tA, tB, ia([s[0] for s in shapes]), ia([s[1] for s in shapes]), ia([s[2] for s in shapes]), C.c_float(0.5), pa(As),
+                                 ia([a.shape[1] for a in As]), pa(Bs), ia([b.shape[1] for b in Bs]), C.c_float(2.0), pa(Cs), ia([s[1] for s in shapes]),
+                                 _st()) == 0
+    torch.cuda.synchronize()
+    for k, (c, r) in enumerate(zip(Cs, first)):
+        assert torch.equal(c, r), (k, shapes[k])
+    assert L.yk_gemm_f32_grouped(0, tA, tB, None, None, None, C.c_float(1), None, None, None, None, C.c_float(0), None, None, _st()) == 0
+
+
 @pytest.mark.parametrize('stride,pad', [(1, (1, 1)), (2, (1, 1)), (2, (1, 0))])
 def test_conv3x3_im2col_gemm_and_adjoint(stride, pad):
     engine, L = _lib()
@@ -107,6 +150,26 @@ def test_depthwise_forward_and_both_gradients(stride):
     _close(y.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy())
     _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
     _close(dw.cpu().numpy().reshape(3, 3, Cc), wt.grad.numpy())
+
+
+def test_grouped_depthwise_weight_gradients_equal_the_separate_calls_bitwise():
+    engine, L = _lib()
+    rng = np.random.default_rng(3)
+    cases = [(4, 15, 22, 72, 1), (2, 56, 80, 24, 2), (3, 14, 20, 130, 1), (16, 7, 10, 960, 1), (2, 28, 40, 32, 2)] + [(2, 9 + i, 11, 8 + 4 * i, 1 + i % 2) for i in range(35)]
+    xs, dys, refs, outs, geo = [], [], [], [], []
+    for (B, Hi, Wi, Cc, stride) in cases:
+        Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+        x, dy = _cu(rng.normal(size=(B, Hi, Wi, Cc))), _cu(rng.normal(size=(B, Ho, Wo, Cc)))
+        g = (B, Hi, Wi, Cc, Ho, Wo, stride, 1, 1)
+        ref = torch.empty(9, Cc, device='cuda')
+        assert L.yk_dw3x3_bwd_weight_f32(engine._ptr(x), engine._ptr(dy), *[C.c_int(v) for v in g], engine._ptr(ref), _st()) == 0
+        xs.append(x); dys.append(dy); refs.append(ref); outs.append(torch.zeros(9, Cc, device='cuda')); geo += list(g)
+    n = len(cases)
+    pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    assert L.yk_dw3x3_bwd_weight_grouped_f32(n, pa(xs), pa(dys), (C.c_int * (9 * n))(*geo), pa(outs), _st()) == 0, L.yk_last_error()
+    torch.cuda.synchronize()
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), (k, cases[k])
 
 
 @pytest.mark.parametrize('act,alpha,M,Cc', [(ns.ACT_NONE, 0.0, 1000, 24), (ns.ACT_RELU, 0.0, 4097, 96), (ns.ACT_RELU6, 6.0, 700, 130),
