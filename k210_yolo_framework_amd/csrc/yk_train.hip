@@ -1000,6 +1000,182 @@ __global__ void __launch_bounds__(256) bn_apply_bwd_kernel(const float *__restri
     stv<V>(dz + i, o);
 }
 
+// --------------------------------------------------------------------------------------------------------
+// SMALL layers (M <= 1536 rows: the 7x10 layers at 16 images - 14 of the 55 BatchNorms of configs[3]): every launch of the
+// reduce -> finish -> apply chain costs 5 us whatever it does, so ONE workgroup of 1024 threads owns 8 channels and ALL rows and does the
+// whole chain without leaving the launch (round 6).  Thread (row lane of 512, half): a float4 of channels per row, R rows per thread, ALL of
+// them loaded before anything is waited for and kept in registers (a first form with 256 threads sweeping the rows had 32 KB in flight per
+// CU: 16 GB/s, 37 us per launch - r6c58); fixed-order LDS tree.
+//   forward : fold the producer's partial sums -> statistics (+ moving statistics) -> apply (+ residual)          2 launches -> 1
+//   backward: sum g, sum g*xhat over the rows -> dbeta, dgamma -> dz                                               3 launches -> 1
+// --------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(1024) bn_fwd_cols_kernel(const float *__restrict__ z, int M, int C, const double *__restrict__ partial, int chunks,
+                                                           double invM, float eps, const float *__restrict__ gamma, const float *__restrict__ beta, int act,
+                                                           float alpha, float *__restrict__ y, float *__restrict__ mean, float *__restrict__ invstd,
+                                                           float *__restrict__ mm, float *__restrict__ mv, float mom, const float *__restrict__ res) {
+    __shared__ double fold[2][64][8];
+    __shared__ float stat[2][8];
+    const int half = threadIdx.x & 1, rl = threadIdx.x >> 1;
+    const int c4 = blockIdx.x * 8 + half * 4;
+    const bool on = c4 < C;
+    float zv[R][4], rv[R][4];
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = rl + r * 512;
+            if (m < M) {
+                ldv<4>(z + (size_t)m * C + c4, zv[r]);
+                if (res) ldv<4>(res + (size_t)m * C + c4, rv[r]);
+            }
+        }
+    }
+    {
+        const int ch = threadIdx.x & 7, j = (threadIdx.x >> 3) & 1, kl = threadIdx.x >> 4;       // 64 chunk lanes
+        const int c = blockIdx.x * 8 + ch;
+        double a = 0;
+        if (c < C)
+            for (int k = kl; k < chunks; k += 64) a += partial[((size_t)k * 2 + j) * C + c];
+        fold[j][kl][ch] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int ch = threadIdx.x, c = blockIdx.x * 8 + ch;
+        if (c < C) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 64; ++k) {
+                a += fold[0][k][ch];
+                b += fold[1][k][ch];
+            }
+            const double mu = a * invM;
+            double var = b * invM - mu * mu;                 // biased (population) variance, as tf.nn.moments
+            if (var < 0) var = 0;
+            const float fm = (float)mu, fi = (float)(1.0 / sqrt(var + (double)eps));
+            mean[c] = fm;
+            invstd[c] = fi;
+            stat[0][ch] = fm;
+            stat[1][ch] = fi;
+            if (mm && mv) {                                  // as bn_stats_finish_kernel
+                const double Mrows = 1.0 / invM;
+                const double uvar = Mrows > 1.5 ? var * Mrows / (Mrows - 1.0) : var;
+                mm[c] = mm[c] * mom + (float)mu * (1.f - mom);
+                mv[c] = mv[c] * mom + (float)uvar * (1.f - mom);
+            }
+        }
+    }
+    __syncthreads();
+    if (!on) return;
+    float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = stat[0][half * 4 + k];
+        is[k] = stat[1][half * 4 + k];
+    }
+    ldv<4>(gamma + c4, ga);
+    ldv<4>(beta + c4, be);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = rl + r * 512;
+        if (m < M) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = t_act(ga[k] * (zv[r][k] - mu[k]) * is[k] + be[k], act, alpha);
+            if (res) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = rv[r][k] + o[k];
+            }
+            stv<4>(y + (size_t)m * C + c4, o);
+        }
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(1024) bn_bwd_cols_kernel(const float *__restrict__ z, const float *__restrict__ dy, int M, int C, float invM,
+                                                           const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int act, float alpha, float *__restrict__ dz,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[2][512][8];
+    const int half = threadIdx.x & 1, rl = threadIdx.x >> 1;
+    const int c = blockIdx.x * 8 + half * 4;
+    const bool on = c < C;
+    float mu[4], is[4], ga[4], be[4], s0[4], s1[4];
+    float xh[R][4], g[R][4];                                  // kept for the second half: z and dy are read once
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mu[k] = is[k] = ga[k] = be[k] = s0[k] = s1[k] = 0.f;
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = rl + r * 512;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xh[r][k] = g[r][k] = 0.f;
+            if (m < M) {
+                ldv<4>(z + (size_t)m * C + c, xh[r]);
+                ldv<4>(dy + (size_t)m * C + c, g[r]);
+            }
+        }
+        ldv<4>(mean + c, mu);
+        ldv<4>(invstd + c, is);
+        ldv<4>(gamma + c, ga);
+        ldv<4>(beta + c, be);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (rl + r * 512 < M) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float x = (xh[r][k] - mu[k]) * is[k];
+                    const float gg = g[r][k] * t_act_grad(ga[k] * x + be[k], act, alpha);
+                    xh[r][k] = x;
+                    g[r][k] = gg;
+                    s0[k] += gg;
+                    s1[k] += gg * x;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[0][rl][half * 4 + k] = s0[k];
+        red[1][rl][half * 4 + k] = s1[k];
+    }
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {                      // fixed-order tree over the 512 row lanes
+        if (rl < o) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                red[0][rl][half * 4 + k] += red[0][rl + o][half * 4 + k];
+                red[1][rl][half * 4 + k] += red[1][rl + o][half * 4 + k];
+            }
+        }
+        __syncthreads();
+    }
+    if (!on) return;
+    float db[4], dg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        db[k] = red[0][0][half * 4 + k];
+        dg[k] = red[1][0][half * 4 + k];
+    }
+    if (rl == 0) {
+        stv<4>(dbeta + c, db);
+        if (dgamma) stv<4>(dgamma + c, dg);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = rl + r * 512;
+        if (m < M) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[r][k] - db[k] * invM - xh[r][k] * dg[k] * invM);     // = bn_apply_bwd_kernel
+            stv<4>(dz + (size_t)m * C + c, o);
+        }
+    }
+}
+static bool bn_cols_ok(long long M, int C, const void *a, const void *b, const void *c) {
+    // R = 3 rows per thread only: at 4 480 rows (R = 9) a workgroup pulls 287 KB in 32-byte row pieces through ONE CU's L1 and takes 27 / 18 us
+    // against 16 / 11 us for the separate launches that spread the same bytes over the chip (r6c58)
+    return M <= 3 * 512 && C % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
 static int bn_chunking(size_t M, int C, int *rows_per_chunk, int *cwl) {
     *cwl = lane_split(C);
     const int RL = 256 >> *cwl;
@@ -1053,6 +1229,12 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
                                    float *dbeta, void *stream) {
     int dev = yk_current_device();
     if (dev < 0) return YK_ERR_NO_DEVICE;
+    if (bn_cols_ok(M, C, z, dy, dz) && dgamma && (((uintptr_t)dgamma | (uintptr_t)dbeta | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15) == 0) {
+        hipLaunchKernelGGL(bn_bwd_cols_kernel<3>, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, z, dy, (int)M, C, 1.f / (float)M, save_mean,
+                           save_invstd, gamma, beta, act, alpha, dz, dgamma, dbeta);
+        YK_HIP(hipGetLastError());
+        return YK_OK;
+    }
     int rpc, cwl;
     const int chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
     float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
@@ -1177,6 +1359,12 @@ __global__ void __launch_bounds__(256) dw_fwd_stats_kernel(conv_geom q, const fl
 static int bn_finish_apply(const float *z, long long M, int C, const double *partial, int chunks, const float *gamma, const float *beta, float eps, int act,
                            float alpha, float *y, float *save_mean, float *save_invstd, float *moving_mean, float *moving_var, float momentum,
                            const float *res, hipStream_t st) {
+    if (bn_cols_ok(M, C, z, y, res) && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+        hipLaunchKernelGGL(bn_fwd_cols_kernel<3>, dim3((C + 7) / 8), dim3(1024), 0, st, z, (int)M, C, partial, chunks, 1.0 / (double)M, eps, gamma, beta, act,
+                           alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res);
+        YK_HIP(hipGetLastError());
+        return YK_OK;
+    }
     if (chunks > 1024)
         hipLaunchKernelGGL(bn_stats_finish_kernel<4>, dim3(C), dim3(256), 0, st, partial, chunks, C, 1.0 / (double)M, eps, save_mean, save_invstd,
                            moving_mean, moving_var, momentum);

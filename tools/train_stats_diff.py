@@ -1,5 +1,5 @@
 """Per-kernel comparison of two rocprofv3 kernel_stats.csv of the training step: python tools/train_stats_diff.py new.csv old.csv [replays_new replays_old]
-(per-step figures: calls and microseconds divided by the number of graph replays + eager steps in the trace; default = calls of bn_apply_bwd / 55)."""
+(per-step figures: calls and microseconds divided by the number of graph replays + eager steps in the trace; default = calls of yolo_loss_kernel / 2)."""
 import csv, sys
 def load(p):
     d = {}
@@ -8,8 +8,8 @@ def load(p):
     return d
 new, old = load(sys.argv[1]), load(sys.argv[2])
 def steps(d):
-    k = [v for n, v in d.items() if 'bn_apply_bwd_kernel<4>' in n]
-    return k[0][0] / 55.0
+    k = [v for n, v in d.items() if n.startswith('yolo_loss_kernel')]
+    return k[0][0] / 2.0                                    # two output layers per step
 na = float(sys.argv[3]) if len(sys.argv) > 3 else steps(new)
 oa = float(sys.argv[4]) if len(sys.argv) > 4 else steps(old)
 keys = sorted(set(new) | set(old), key=lambda k: -(new.get(k, (0, 0, 0))[2] / na + old.get(k, (0, 0, 0))[2] / oa))
