@@ -1170,6 +1170,58 @@ __global__ void __launch_bounds__(1024) bn_bwd_cols_kernel(const float *__restri
         }
     }
 }
+// The backward column reduction with float4 lanes (round 6): block = CW channel-quad lanes x RL row lanes (CW = C / 4, any number <= 256), a
+// thread walks ~8 rows of its chunk with two 16-byte loads per row.  The scalar form above gave the 112x160 layers (C = 16-32: one channel
+// group) 512 workgroups of 70-iteration threads with 4-byte loads: 40 us for 73 MB (1.8 TB/s).  partial: [chunk][2][C] floats.
+__global__ void __launch_bounds__(256) bn_colreduce_bwd_v4_kernel(const float *__restrict__ z, const float *__restrict__ dy, uint32_t M, int C, int rows_per_chunk,
+                                                                  int CW, int RL, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, int act, float alpha,
+                                                                  float *__restrict__ partial) {
+    __shared__ float red[2][256][4];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = (blockIdx.y * CW + cl) * 4;
+    const uint32_t r0 = blockIdx.x * (uint32_t)rows_per_chunk, r1 = min(M, r0 + (uint32_t)rows_per_chunk);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < RL && c < C) {
+        float mu[4], is[4], ga[4], be[4];
+        ldv<4>(mean + c, mu);
+        ldv<4>(invstd + c, is);
+        ldv<4>(gamma + c, ga);
+        ldv<4>(beta + c, be);
+#pragma unroll 4
+        for (uint32_t m = r0 + rl; m < r1; m += RL) {
+            float zv[4], gy[4];
+            ldv<4>(z + (size_t)m * C + c, zv);
+            ldv<4>(dy + (size_t)m * C + c, gy);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (zv[k] - mu[k]) * is[k];
+                const float g = gy[k] * t_act_grad(ga[k] * xh + be[k], act, alpha);
+                s0[k] += g;
+                s1[k] += g * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[0][threadIdx.x][k] = s0[k];
+        red[1][threadIdx.x][k] = s1[k];
+    }
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RL; ++r) {
+                a += red[0][r * CW + cl][k];
+                b += red[1][r * CW + cl][k];
+            }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c + k] = a;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c + k] = b;
+        }
+    }
+}
+
 static bool bn_cols_ok(long long M, int C, const void *a, const void *b, const void *c) {
     // R = 3 rows per thread only: at 4 480 rows (R = 9) a workgroup pulls 287 KB in 32-byte row pieces through ONE CU's L1 and takes 27 / 18 us
     // against 16 / 11 us for the separate launches that spread the same bytes over the chip (r6c58)
@@ -1235,13 +1287,28 @@ extern "C" int yk_bn_train_bwd_f32(const float *z, const float *dy, long long M,
         YK_HIP(hipGetLastError());
         return YK_OK;
     }
-    int rpc, cwl;
-    const int chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
-    float *partial = (float *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
-    if (!partial) return YK_ERR_NOMEM;
+    int rpc, cwl, chunks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_colreduce_kernel<false>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, dy, (size_t)M, C, rpc, cwl,
-                       save_mean, save_invstd, gamma, beta, act, alpha, (void *)partial);
+    float *partial;
+    // (only the large layers: below ~50 000 rows the scalar form's launches are at the 5-9 us floor and the 8-row threads of this one are not: r6c62)
+    const bool v4 = C % 4 == 0 && M >= 50000 && M < (1ll << 31) &&
+                    (((uintptr_t)z | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15) == 0;
+    if (v4) {
+        const int CV = C / 4, CW = std::min(CV, 256), RL = 256 / CW, groups = (CV + CW - 1) / CW;
+        chunks = (int)std::min<long long>(2048, (M + RL * 8 - 1) / (RL * 8));                   // ~8 rows per thread
+        rpc = (int)(((M + chunks - 1) / chunks + RL - 1) / RL * RL);
+        chunks = (int)((M + rpc - 1) / rpc);
+        partial = (float *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
+        if (!partial) return YK_ERR_NOMEM;
+        hipLaunchKernelGGL(bn_colreduce_bwd_v4_kernel, dim3(chunks, groups), dim3(256), 0, st, z, dy, (uint32_t)M, C, rpc, CW, RL, save_mean, save_invstd, gamma,
+                           beta, act, alpha, partial);
+    } else {
+        chunks = bn_chunking((size_t)M, C, &rpc, &cwl);
+        partial = (float *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
+        if (!partial) return YK_ERR_NOMEM;
+        hipLaunchKernelGGL(bn_colreduce_kernel<false>, dim3(chunks, (C + (1 << cwl) - 1) >> cwl), dim3(256), 0, st, z, dy, (size_t)M, C, rpc, cwl,
+                           save_mean, save_invstd, gamma, beta, act, alpha, (void *)partial);
+    }
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const float *)partial, chunks, C, dbeta, dgamma);
     const size_t total = (size_t)M * C;
     if (C % 4 == 0)
