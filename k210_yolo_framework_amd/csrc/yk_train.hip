@@ -1499,10 +1499,13 @@ extern "C" int yk_dw3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi
         return YK_ERR_ARG;
     }
     const int V = C % 4 == 0 ? 4 : 1, CV = C / V;
-    const int CW = std::min(CV, 256), RL = 256 / CW, groups = (CV + CW - 1) / CW;
-    // ~4 rows per thread (a thread's rows are a serial chain of load -> multiply-add -> store: 16 rows per thread measured 37-61 us per launch
-    // whatever the size, r6c44), at most 8192 chunks (past 1024 the wide finishing kernel folds them)
-    int chunks = (int)std::min<long long>(8192, (M + RL * 4 - 1) / (RL * 4));
+    // channel lanes: at most 64 per workgroup, the groups of equal width (144 float4 lanes = 3 x 48 with 5 row lanes; one group of 144 would leave one row
+    // lane and 112 idle threads)
+    const int groups = (CV + 63) / 64, CW = (CV + groups - 1) / groups, RL = 256 / CW;
+    // ~4 rows per thread, 2 for the small layers (a thread's rows are a serial chain of load -> multiply-add -> store: 16 rows per thread measured
+    // 37-61 us per launch whatever the size, r6c44), at most 8192 chunks (past 1024 the wide finishing kernel folds them)
+    const int rpt = M <= 8192 ? 2 : 4;
+    int chunks = (int)std::min<long long>(8192, (M + RL * rpt - 1) / (RL * rpt));
     const int rpc = (int)(((M + chunks - 1) / chunks + RL - 1) / RL * RL);
     chunks = (int)((M + rpc - 1) / rpc);
     double *partial = (double *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * C + sizeof(float) * C);
