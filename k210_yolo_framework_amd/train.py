@@ -384,9 +384,12 @@ class Trainer:
                         else:
                             on_side(lambda dz=dz, x=x, gw=gw, co=co, ci=ci, M=M: self.gemm(1, 0, co, ci, M, dz, co, x, ci, gw, ci), dz)     # dW = dZ^T * X
                         if need_dx:
-                            dx = self._new(self.B, hi, wi, ci)
-                            self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)           # dX = dZ * W
-                            acc(op['in0'], dx, True)
+                            if op['in0'] in D:                                          # a second reader of the input: dX += dZ * W straight into the
+                                self.gemm(0, 0, M, ci, co, dz, co, w, ci, D[op['in0']], ci, beta=1.0)   # accumulated gradient (no temporary, no axpy)
+                            else:
+                                dx = self._new(self.B, hi, wi, ci)
+                                self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)       # dX = dZ * W
+                                acc(op['in0'], dx, True)
                     else:
                         kk = 9 * ci
                         col = self._new(M, kk)
