@@ -316,6 +316,17 @@ int yk_im2col3x3_f32(const float *x, int B, int Hi, int Wi, int C, int Ho, int W
                      float *col, void *stream);
 int yk_col2im3x3_f32(const float *col, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t, int pad_l,
                      float *dx, void *stream);
+/* 3x3 Conv2D as an implicit GEMM (no column matrix); weights [Co][9 * Ci] (k = (ky*3+kx)*Ci + c).  Needs Ci % 4 == 0 (Co % 4 == 0 too for the
+ * gradients; stride 1 for the data gradient) and 16-byte aligned tensors - YK_ERR_UNSUPPORTED otherwise (the im2col path above covers those).
+ * yk_conv3x3_bn_fwd_f32: z = conv(x); with gamma != NULL also BatchNormalization(training) + activation (+ residual) -> y, as yk_gemm_bn_fwd_f32.
+ * Forward and weight gradient add in the order of im2col + yk_gemm_f32: bitwise the same result. */
+int yk_conv3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l, int Co,
+                          float *z, const float *gamma, const float *beta, float eps, int act, float alpha, float *y, float *save_mean,
+                          float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream);
+int yk_conv3x3_bwd_weight_f32(const float *x, const float *dz, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                              int Co, float *dw, void *stream);
+int yk_conv3x3_bwd_data_f32(const float *dz, const float *w, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l, int Co,
+                            float *dx, void *stream);
 /* DepthwiseConv2D 3x3, weights [9][C] */
 int yk_dw3x3_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int C, int Ho, int Wo, int stride, int pad_t,
                      int pad_l, float *y, void *stream);

@@ -23,8 +23,21 @@ struct gemm_v2_lds {
     static constexpr int FLOATS = 2 * (SA + SB);
 };
 // one 64x64 tile (tile indices bx, by; K slice bz) of the problem g; lds: gemm_v2_lds<TA, TB>::FLOATS floats, 16-byte aligned
-template <bool TA, bool TB, bool VEC, bool STATS>
-__device__ __forceinline__ void gemm_f32_v2_tile(const gemm_args g, const int bx, const int by, const int bz, float *__restrict__ lds) {   // g BY VALUE: a reference to the kernel's argument struct put it on the stack (scratch loads in the k loop)
+// CONV (round 6): a 3x3 convolution WITHOUT the column matrix - the operand that im2col would have written is gathered by the loader
+// (16-byte pieces: a float4 of channels never straddles a tap because Cin % 4 == 0):
+//   1  forward          Z  = col(X) * W^T         TA = 0, TB = 1   A[m][k]:  m -> (b, oy, ox), k -> (tap, c): X at the tap's input pixel, or zeros
+//   2  weight gradient  dW = dZ^T * col(X)        TA = 1, TB = 0   B[k][n]:  k -> pixel, n -> (tap, c)
+//   3  data gradient    dX = col'(dZ) * W'        TA = 0, TB = 0   A[m][k']: m -> input pixel, k' -> (tap, co): dZ at the output pixel that tap
+//                       (stride 1)                                 connects to it; B[k'][n] = W[co][tap][n]
+// Forward and weight gradient add in the same order as im2col + GEMM (bitwise the same result).
+struct conv_args {
+    conv_geom q;
+    int co;
+};
+template <bool TA, bool TB, bool VEC, bool STATS, int CONV = 0>
+__device__ __forceinline__ void gemm_f32_v2_tile(const gemm_args g, const int bx, const int by, const int bz, float *__restrict__ lds,
+                                                 const conv_args cv = conv_args()) {   // g BY VALUE: a reference to the kernel's argument struct put it on the stack (scratch loads in the k loop)
+    static_assert(CONV == 0 || VEC, "the gathered operands are loaded 16 bytes at a time");
     constexpr int BK = 32, LDM = 34, LDK = 80;
     constexpr int SA = gemm_v2_lds<TA, TB>::SA, SB = gemm_v2_lds<TA, TB>::SB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -53,7 +66,23 @@ __device__ __forceinline__ void gemm_f32_v2_tile(const gemm_args g, const int bx
                 const int m = TA ? m0 + q : m0 + r, k = TA ? k0 + r : k0 + q;
                 const float *p = TA ? g.A + (size_t)k * g.lda + m : g.A + (size_t)m * g.lda + k;
                 floatx4t v = {0.f, 0.f, 0.f, 0.f};
-                if (VEC) {
+                if (CONV == 1 || CONV == 3) {
+                    // m -> pixel (b, y, x): of the OUTPUT (1) / of the INPUT (3);  k -> (tap, channel)
+                    const int W_ = CONV == 1 ? cv.q.Wo : cv.q.Wi, H_ = CONV == 1 ? cv.q.Ho : cv.q.Hi, CK = CONV == 1 ? cv.q.C : cv.co;
+                    const int row = m / W_, px = m - row * W_, b = row / H_, py = row - b * H_;
+                    const int tap = k / CK, c = k - tap * CK, ky = tap / 3, kx = tap - ky * 3;
+                    if (m < g.M && k < g.K) {
+                        if (CONV == 1) {
+                            const int iy = py * cv.q.stride - cv.q.pad_t + ky, ix = px * cv.q.stride - cv.q.pad_l + kx;
+                            if ((unsigned)iy < (unsigned)cv.q.Hi && (unsigned)ix < (unsigned)cv.q.Wi)
+                                v = *reinterpret_cast<const floatx4t *>(g.A + (((size_t)b * cv.q.Hi + iy) * cv.q.Wi + ix) * cv.q.C + c);
+                        } else {
+                            const int oy = py + cv.q.pad_t - ky, ox = px + cv.q.pad_l - kx;
+                            if ((unsigned)oy < (unsigned)cv.q.Ho && (unsigned)ox < (unsigned)cv.q.Wo)
+                                v = *reinterpret_cast<const floatx4t *>(g.A + (((size_t)b * cv.q.Ho + oy) * cv.q.Wo + ox) * cv.co + c);
+                        }
+                    }
+                } else if (VEC) {
                     if (m < g.M && k < g.K) v = *reinterpret_cast<const floatx4t *>(p);
                 } else {
 #pragma unroll
@@ -70,7 +99,18 @@ __device__ __forceinline__ void gemm_f32_v2_tile(const gemm_args g, const int bx
                 const int n = TB ? n0 + r : n0 + q, k = TB ? k0 + q : k0 + r;
                 const float *p = TB ? g.B + (size_t)n * g.ldb + k : g.B + (size_t)k * g.ldb + n;
                 floatx4t v = {0.f, 0.f, 0.f, 0.f};
-                if (VEC) {
+                if (CONV == 2) {
+                    // k -> output pixel (b, oy, ox);  n -> (tap, channel): X at the tap's input pixel
+                    const int row = k / cv.q.Wo, ox = k - row * cv.q.Wo, b = row / cv.q.Ho, oy = row - b * cv.q.Ho;
+                    const int tap = n / cv.q.C, c = n - tap * cv.q.C, ky = tap / 3, kx = tap - ky * 3;
+                    const int iy = oy * cv.q.stride - cv.q.pad_t + ky, ix = ox * cv.q.stride - cv.q.pad_l + kx;
+                    if (n < g.N && k < g.K && (unsigned)iy < (unsigned)cv.q.Hi && (unsigned)ix < (unsigned)cv.q.Wi)
+                        v = *reinterpret_cast<const floatx4t *>(g.B + (((size_t)b * cv.q.Hi + iy) * cv.q.Wi + ix) * cv.q.C + c);
+                } else if (CONV == 3) {
+                    // k' -> (tap, co): row co of W [co][9 * ci], the tap's ci entries
+                    const int tap = k / cv.co, cc = k - tap * cv.co;
+                    if (n < g.N && k < g.K) v = *reinterpret_cast<const floatx4t *>(g.B + ((size_t)cc * 9 + tap) * cv.q.C + n);
+                } else if (VEC) {
                     if (n < g.N && k < g.K) v = *reinterpret_cast<const floatx4t *>(p);
                 } else {
 #pragma unroll
@@ -191,6 +231,12 @@ template <bool TA, bool TB, bool VEC, bool STATS = false>
 __global__ void __launch_bounds__(256) gemm_f32_v2_kernel(const gemm_args g) {
     __shared__ __attribute__((aligned(16))) float lds[gemm_v2_lds<TA, TB>::FLOATS];
     gemm_f32_v2_tile<TA, TB, VEC, STATS>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+template <bool TA, bool TB, bool STATS, int CONV>
+__global__ void __launch_bounds__(256) gemm_f32_conv_kernel(const gemm_args g, const conv_args cv) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_v2_lds<TA, TB>::FLOATS];
+    gemm_f32_v2_tile<TA, TB, true, STATS, CONV>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds, cv);
 }
 
 // GROUPED launch (round 6): up to YK_GROUP_MAX independent problems of one layout in ONE launch - the weight gradients of a whole backward

@@ -153,6 +153,9 @@ __global__ void __launch_bounds__(256) splitk_sum16_kernel(const float *__restri
     }
 }
 
+struct conv_geom {
+    int B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l;
+};
 #include "yk_gemm_f32.h"
 
 static int gemm_splits(int M, int N, int K) {
@@ -422,10 +425,6 @@ extern "C" int yk_l2_segments_f32(const float *params, float *grads, const long 
 // --------------------------------------------------------------------------------------------------------
 // im2col / col2im for 3x3 convs, NHWC.  col: [B*Ho*Wo][9*C] with k = (ky*3+kx)*C + c (matches OHWI weights).
 // --------------------------------------------------------------------------------------------------------
-struct conv_geom {
-    int B, Hi, Wi, C, Ho, Wo, stride, pad_t, pad_l;
-};
-
 __global__ void __launch_bounds__(256) im2col3x3_kernel(conv_geom q, const float *__restrict__ x, float *__restrict__ col) {
     const size_t total = (size_t)q.B * q.Ho * q.Wo * 9 * q.C;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1514,6 +1513,117 @@ extern "C" int yk_dw3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi
     if (V == 4) hipLaunchKernelGGL(dw_fwd_stats_kernel<4>, dim3(chunks, groups), dim3(256), 0, st, q, x, w, z, rpc, CW, RL, partial);
     else hipLaunchKernelGGL(dw_fwd_stats_kernel<1>, dim3(chunks, groups), dim3(256), 0, st, q, x, w, z, rpc, CW, RL, partial);
     return bn_finish_apply(z, M, C, partial, chunks, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res, st);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// 3x3 convolutions as IMPLICIT GEMMs (round 6; yk_gemm_f32.h CONV = 1 / 2 / 3): no column matrix - rounds 2-5 wrote it (113 MB for the 14x20x704
+// head conv), multiplied it, and for the data gradient wrote a column matrix of gradients and folded it (col2im).  Needs Cin % 4 == 0 (and
+// Cout % 4 == 0, stride 1 for the data gradient); the 3-channel stem keeps im2col.
+// --------------------------------------------------------------------------------------------------------
+static int conv_gemm(gemm_args g, const conv_args &cv, int mode, double *stats_partial, int *chunks_out, int *rpc_out, int *cwl_out, int dev, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int s = gemm_splits(g.M, g.N, g.K);
+    g.splitk = s;
+    g.ws = nullptr;
+    g.stats = nullptr;
+    if (s > 1) {
+        g.ws = (float *)yk_scratch(dev, stream, 14, sizeof(float) * (size_t)s * g.M * g.N);
+        if (!g.ws) return YK_ERR_NOMEM;
+    } else if (stats_partial) {
+        g.stats = stats_partial;
+    }
+    const dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, s);
+    if (mode == 1) {
+        if (g.stats) hipLaunchKernelGGL((gemm_f32_conv_kernel<false, true, true, 1>), grid, dim3(256), 0, st, g, cv);
+        else hipLaunchKernelGGL((gemm_f32_conv_kernel<false, true, false, 1>), grid, dim3(256), 0, st, g, cv);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL((gemm_f32_conv_kernel<true, false, false, 2>), grid, dim3(256), 0, st, g, cv);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_conv_kernel<false, false, false, 3>), grid, dim3(256), 0, st, g, cv);
+    }
+    if (s > 1) {
+        const size_t tot = (size_t)g.M * g.N;
+        if (stats_partial)
+            hipLaunchKernelGGL(splitk_sum_stats_kernel, dim3(*chunks_out, (g.N + (1 << *cwl_out) - 1) >> *cwl_out), dim3(256), 0, st, (const float *)g.ws, s, (size_t)g.M, g.N,
+                               g.C, g.ldc, *rpc_out, *cwl_out, stats_partial);
+        else if (s >= 16 && tot <= 65536)
+            hipLaunchKernelGGL(splitk_sum16_kernel, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, st, (const float *)g.ws, s, g.M, g.N, g.alpha, g.beta, g.C, g.ldc);
+        else
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)g.ws, s, g.M, g.N, g.alpha, g.beta, g.C, g.ldc);
+    }
+    YK_HIP(hipGetLastError());
+    return YK_OK;
+}
+static bool conv3x3_ok(const char *who, const void *a, const void *b, const void *c, int B, int Ci, int Co, bool need_co4) {
+    if (!a || !b || !c || B <= 0 || Ci <= 0 || Co <= 0) {
+        yk_set_error("%s: bad argument", who);
+        return false;
+    }
+    if (Ci % 4 || (need_co4 && Co % 4) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15)) {
+        yk_set_error("%s: needs Cin %% 4 == 0%s and 16-byte aligned tensors (use yk_im2col3x3_f32 + yk_gemm_f32 otherwise)", who, need_co4 ? ", Cout % 4 == 0" : "");
+        return false;
+    }
+    return true;
+}
+// z = conv3x3(x, w) [+ BatchNormalization(training) + activation (+ residual) -> y when gamma is given, as yk_gemm_bn_fwd_f32]; w: [Co][9 * Ci]
+extern "C" int yk_conv3x3_bn_fwd_f32(const float *x, const float *w, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l, int Co,
+                                     float *z, const float *gamma, const float *beta, float eps, int act, float alpha, float *y, float *save_mean,
+                                     float *save_invstd, float *moving_mean, float *moving_var, float momentum, const float *res, void *stream) {
+    if (!conv3x3_ok("yk_conv3x3_bn_fwd_f32", x, w, z, B, Ci, Co, false)) return (Ci % 4) ? YK_ERR_UNSUPPORTED : YK_ERR_ARG;
+    if (gamma && (!beta || !y || !save_mean || !save_invstd)) {
+        yk_set_error("yk_conv3x3_bn_fwd_f32: bad BatchNormalization argument");
+        return YK_ERR_ARG;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    const long long Mll = (long long)B * Ho * Wo;
+    if (Mll >= (1ll << 31) / 9) {
+        yk_set_error("yk_conv3x3_bn_fwd_f32: too many pixels");
+        return YK_ERR_ARG;
+    }
+    const int M = (int)Mll;
+    gemm_args g;
+    g.M = M; g.N = Co; g.K = 9 * Ci; g.lda = 9 * Ci; g.ldb = 9 * Ci; g.ldc = Co; g.transA = 0; g.transB = 1;
+    g.alpha = 1.f; g.beta = 0.f; g.A = x; g.B = w; g.C = z;
+    conv_args cv = {{B, Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l}, Co};
+    if (!gamma) return conv_gemm(g, cv, 1, nullptr, nullptr, nullptr, nullptr, dev, stream);
+    const int s = gemm_splits(M, Co, 9 * Ci), mt = (M + 63) / 64;
+    int rpc = 0, cwl = 0;
+    int chunks = s > 1 ? bn_chunking((size_t)M, Co, &rpc, &cwl) : mt;
+    double *partial = (double *)yk_scratch(dev, stream, 13, sizeof(double) * (size_t)chunks * 2 * Co + sizeof(float) * Co);
+    if (!partial) return YK_ERR_NOMEM;
+    const int rc = conv_gemm(g, cv, 1, partial, &chunks, &rpc, &cwl, dev, stream);
+    if (rc != YK_OK) return rc;
+    return bn_finish_apply(z, M, Co, partial, chunks, gamma, beta, eps, act, alpha, y, save_mean, save_invstd, moving_mean, moving_var, momentum, res,
+                           (hipStream_t)stream);
+}
+// dw [Co][9 * Ci] = dz^T * col(x)      (tf Conv2DBackpropFilter)
+extern "C" int yk_conv3x3_bwd_weight_f32(const float *x, const float *dz, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l,
+                                         int Co, float *dw, void *stream) {
+    if (!conv3x3_ok("yk_conv3x3_bwd_weight_f32", x, dz, dw, B, Ci, Co, true)) return (Ci % 4 || Co % 4) ? YK_ERR_UNSUPPORTED : YK_ERR_ARG;
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    gemm_args g;
+    g.M = Co; g.N = 9 * Ci; g.K = B * Ho * Wo; g.lda = Co; g.ldb = 9 * Ci; g.ldc = 9 * Ci; g.transA = 1; g.transB = 0;
+    g.alpha = 1.f; g.beta = 0.f; g.A = dz; g.B = x; g.C = dw;
+    conv_args cv = {{B, Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l}, Co};
+    return conv_gemm(g, cv, 2, nullptr, nullptr, nullptr, nullptr, dev, stream);
+}
+// dx = the transposed convolution of dz (stride 1)      (tf Conv2DBackpropInput)
+extern "C" int yk_conv3x3_bwd_data_f32(const float *dz, const float *w, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int stride, int pad_t, int pad_l, int Co,
+                                       float *dx, void *stream) {
+    if (!conv3x3_ok("yk_conv3x3_bwd_data_f32", dz, w, dx, B, Ci, Co, true)) return (Ci % 4 || Co % 4) ? YK_ERR_UNSUPPORTED : YK_ERR_ARG;
+    if (stride != 1) {
+        yk_set_error("yk_conv3x3_bwd_data_f32: stride %d (only stride 1; use yk_gemm_f32 + yk_col2im3x3_f32)", stride);
+        return YK_ERR_UNSUPPORTED;
+    }
+    int dev = yk_current_device();
+    if (dev < 0) return YK_ERR_NO_DEVICE;
+    gemm_args g;
+    g.M = B * Hi * Wi; g.N = Ci; g.K = 9 * Co; g.lda = 9 * Co; g.ldb = Ci; g.ldc = Ci; g.transA = 0; g.transB = 0;
+    g.alpha = 1.f; g.beta = 0.f; g.A = dz; g.B = w; g.C = dx;
+    conv_args cv = {{B, Hi, Wi, Ci, Ho, Wo, stride, pad_t, pad_l}, Co};
+    return conv_gemm(g, cv, 3, nullptr, nullptr, nullptr, nullptr, dev, stream);
 }
 
 // bias add (+ optional column sum of the gradient for the bias) for the two biased output convs

@@ -72,7 +72,7 @@ def lib() -> C.CDLL:
         for fn in ('yk_plan_create', 'yk_plan_create_ex', 'yk_run_u8', 'yk_run_f32', 'yk_get_output', 'yk_debug_read_tensor',
                    'yk_plan_launch_count', 'yk_plan_launch_info', 'yk_plan_check', 'yk_plan_peek_error', 'yk_plan_debug_set_error', 'yk_plan_profile', 'yk_decode_py', 'yk_decode_py_ex', 'yk_decode_py_packed',
                    'yk_graph_begin', 'yk_graph_end', 'yk_graph_launch', 'yk_graph_node_count', 'yk_graph_kernel_node_count', 'yk_memcpy_async', 'yk_host_device_ptr', 'yk_stream_create', 'yk_stream_destroy', 'yk_stream_query_priority', 'yk_normalise_u8', 'yk_region_batched', 'yk_yolo_loss', 'yk_letterbox_u8',
-                   'region_layer_init', 'yk_gemm_f32', 'yk_gemm_f32_grouped', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_dw3x3_fwd_f32',
+                   'region_layer_init', 'yk_gemm_f32', 'yk_gemm_f32_grouped', 'yk_im2col3x3_f32', 'yk_col2im3x3_f32', 'yk_conv3x3_bn_fwd_f32', 'yk_conv3x3_bwd_weight_f32', 'yk_conv3x3_bwd_data_f32', 'yk_dw3x3_fwd_f32',
                    'yk_dw3x3_bwd_data_f32', 'yk_dw3x3_bwd_weight_f32', 'yk_dw3x3_bwd_weight_grouped_f32', 'yk_bn_train_fwd_f32', 'yk_bn_train_fwd_res_f32', 'yk_gemm_bn_fwd_f32', 'yk_dw3x3_bn_fwd_f32', 'yk_l2_segments_f32', 'yk_bn_train_bwd_f32',
                    'yk_bias_add_f32', 'yk_colsum_f32', 'yk_upsample2x_bwd_f32', 'yk_maxpool2_fwd_f32',
                    'yk_maxpool2_bwd_f32', 'yk_axpy_f32', 'yk_adam_f32', 'yk_dot_f32'):

@@ -93,6 +93,7 @@ class Trainer:
         # together - 35 GEMMs + 35 slice-adding launches become 2, the depthwise weight gradients (17 + 17) 2 more.  YK_TRAIN_GROUP_WGRAD=0: one launch
         # per layer as before.
         self.group_wgrad = (_os.environ.get('YK_TRAIN_GROUP_WGRAD', '1') or '1') != '0' and not self.wgrad_stream
+        self.implicit3x3 = (_os.environ.get('YK_TRAIN_IMPLICIT3X3', '1') or '1') != '0'     # 3x3 convs as implicit GEMMs (0: im2col + GEMM + col2im, rounds 2-5)
         self._ws = None
         self._l2_seg = None
         self._fa = None
@@ -225,14 +226,17 @@ class Trainer:
                 w = self.view(self.P, l.name + '/kernel')
                 z = self._new(self.B, ho, wo, co)
                 a = kk = None
+                implicit = False                                   # 3x3 conv as an implicit GEMM: no column matrix (needs Cin % 4 == 0: not the 3-channel stem)
                 if t == ns.OP_CONV:
                     ci, k = op['cin'], op['k']
                     if k == 1 and op['stride'] == 1:
                         a, kk = x, ci
                     else:
                         assert k == 3
-                        a, kk = self._new(M, 9 * ci), 9 * ci
-                        self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(a), self._s()), 'yk_im2col3x3_f32')
+                        implicit = self.implicit3x3 and ci % 4 == 0 and bool(l.bn_name)
+                        if not implicit:
+                            a, kk = self._new(M, 9 * ci), 9 * ci
+                            self._ck(self.L.yk_im2col3x3_f32(engine._ptr(x), *self._geom(op), engine._ptr(a), self._s()), 'yk_im2col3x3_f32')
                 if l.bn_name:
                     # convolution + batch statistics + apply in one library call: the producer of z leaves the partial sums of the
                     # statistics (yk_gemm_bn_fwd_f32 / yk_dw3x3_bn_fwd_f32), z is not read a second time for them
@@ -246,7 +250,9 @@ class Trainer:
                           engine._ptr(self.moving[l.bn_name + '/moving_mean']), engine._ptr(self.moving[l.bn_name + '/moving_variance']),
                           C.c_float(BN_MOMENTUM_V2 if self.spec.name == 'yolo_mobilev2' and not _is_darknet_conv(l.name) else BN_MOMENTUM),
                           engine._ptr(res) if res is not None else None, self._s())
-                    if t == ns.OP_CONV:
+                    if implicit:
+                        self._ck(self.L.yk_conv3x3_bn_fwd_f32(engine._ptr(x), engine._ptr(w), *self._geom(op), C.c_int(co), *bn), 'yk_conv3x3_bn_fwd_f32')
+                    elif t == ns.OP_CONV:
                         self._ck(self.L.yk_gemm_bn_fwd_f32(C.c_int(M), C.c_int(co), C.c_int(kk), engine._ptr(a), C.c_int(kk), engine._ptr(w),
                                                            C.c_int(kk), *bn), 'yk_gemm_bn_fwd_f32')           # Z = X * W^T
                     else:
@@ -390,6 +396,22 @@ class Trainer:
                                 dx = self._new(self.B, hi, wi, ci)
                                 self.gemm(0, 0, M, ci, co, dz, co, w, ci, dx, ci)       # dX = dZ * W
                                 acc(op['in0'], dx, True)
+                    elif self.implicit3x3 and ci % 4 == 0 and co % 4 == 0:
+                        geom = self._geom(op)
+                        on_side(lambda x=x, dz=dz, gw=gw, geom=geom, co=co: self._ck(self.L.yk_conv3x3_bwd_weight_f32(
+                            engine._ptr(x), engine._ptr(dz), *geom, C.c_int(co), engine._ptr(gw), self._s()), 'yk_conv3x3_bwd_weight_f32'), dz)
+                        if need_dx:
+                            dx = self._new(self.B, hi, wi, ci)
+                            if op['stride'] == 1:
+                                self._ck(self.L.yk_conv3x3_bwd_data_f32(engine._ptr(dz), engine._ptr(w), *geom, C.c_int(co), engine._ptr(dx), self._s()),
+                                         'yk_conv3x3_bwd_data_f32')
+                            else:                                           # strided: column matrix of gradients, folded by col2im
+                                kk = 9 * ci
+                                col = self._new(M, kk)
+                                self.gemm(0, 0, M, kk, co, dz, co, w, kk, col, kk)
+                                self._ck(self.L.yk_col2im3x3_f32(engine._ptr(col), *geom, engine._ptr(dx), self._s()), 'yk_col2im3x3_f32')
+                                del col
+                            acc(op['in0'], dx, True)
                     else:
                         kk = 9 * ci
                         col = self._new(M, kk)

@@ -128,6 +128,73 @@ def test_conv3x3_im2col_gemm_and_adjoint(stride, pad):
     _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
 
 
+@pytest.mark.parametrize('stride,pad,B,Hi,Wi,Ci,Co', [(1, (1, 1), 3, 13, 18, 8, 12), (2, (1, 1), 2, 15, 22, 12, 20), (2, (1, 0), 2, 14, 20, 4, 8),
+                                                     (1, (1, 1), 16, 7, 10, 64, 36), (1, (1, 1), 4, 14, 20, 48, 16)])
+def test_conv3x3_implicit_gemm_forward_and_gradients(stride, pad, B, Hi, Wi, Ci, Co):
+    """The 3x3 convolution without the column matrix (yk_conv3x3_*): against float64 autograd, and forward / weight gradient bit for bit against
+    im2col + yk_gemm_f32 (same order of additions); with BatchNorm the fused call equals conv + yk_bn_train_fwd_res_f32."""
+    engine, L = _lib()
+    rng = np.random.default_rng(stride + Ci)
+    pt, pl = pad[0], pad[0]
+    pb = pr = pad[1]
+    Ho, Wo = (Hi + pt + pb - 3) // stride + 1, (Wi + pl + pr - 3) // stride + 1
+    x = rng.normal(size=(B, Hi, Wi, Ci)).astype(np.float32)
+    w = rng.normal(size=(3, 3, Ci, Co)).astype(np.float32)
+    dy = rng.normal(size=(B, Ho, Wo, Co)).astype(np.float32)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    yt = F.conv2d(F.pad(xt, (pl, pr, pt, pb)), wt.permute(3, 2, 0, 1), stride=stride)
+    yt.backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    M, KK = B * Ho * Wo, 9 * Ci
+    geom = [C.c_int(v) for v in (B, Hi, Wi, Ci, Ho, Wo, stride, pt, pl)]
+    xd, dyd = _cu(x), _cu(dy)
+    wd = _cu(np.transpose(w, (3, 0, 1, 2)).reshape(Co, KK))
+    nobn = [None, None, C.c_float(0), 0, C.c_float(0), None, None, None, None, None, C.c_float(0), None]
+    z = torch.empty(M, Co, device='cuda')
+    assert L.yk_conv3x3_bn_fwd_f32(engine._ptr(xd), engine._ptr(wd), *geom, Co, engine._ptr(z), *nobn, _st()) == 0, L.yk_last_error()
+    _close(z.cpu().numpy().reshape(B, Ho, Wo, Co), yt.detach().permute(0, 2, 3, 1).numpy())
+    col = torch.empty(M, KK, device='cuda')
+    assert L.yk_im2col3x3_f32(engine._ptr(xd), *geom, engine._ptr(col), _st()) == 0
+    z2 = torch.empty(M, Co, device='cuda')
+    assert L.yk_gemm_f32(0, 1, M, Co, KK, C.c_float(1), engine._ptr(col), KK, engine._ptr(wd), KK, C.c_float(0), engine._ptr(z2), Co, _st()) == 0
+    assert torch.equal(z, z2)
+    if Co % 4 == 0:
+        gw, gw2 = torch.empty(Co, KK, device='cuda'), torch.empty(Co, KK, device='cuda')
+        assert L.yk_conv3x3_bwd_weight_f32(engine._ptr(xd), engine._ptr(dyd), *geom, Co, engine._ptr(gw), _st()) == 0, L.yk_last_error()
+        assert L.yk_gemm_f32(1, 0, Co, KK, M, C.c_float(1), engine._ptr(dyd), Co, engine._ptr(col), KK, C.c_float(0), engine._ptr(gw2), KK, _st()) == 0
+        _close(np.transpose(gw.cpu().numpy().reshape(Co, 3, 3, Ci), (1, 2, 3, 0)), wt.grad.numpy())
+        assert torch.equal(gw, gw2)
+        dx = torch.empty(B, Hi, Wi, Ci, device='cuda')
+        rc = L.yk_conv3x3_bwd_data_f32(engine._ptr(dyd), engine._ptr(wd), *geom, Co, engine._ptr(dx), _st())
+        if stride == 1:
+            assert rc == 0, L.yk_last_error()
+            _close(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+        else:
+            assert rc != 0 and b'stride' in L.yk_last_error()
+    # with BatchNorm: the fused call against conv + the separate BatchNorm call
+    gamma, beta = _cu(rng.uniform(0.5, 2, Co)), _cu(rng.normal(size=Co))
+    outs = []
+    for fused in (False, True):
+        zz, y = torch.empty(M, Co, device='cuda'), torch.empty(M, Co, device='cuda')
+        sm, si = torch.empty(Co, device='cuda'), torch.empty(Co, device='cuda')
+        mm, mv = torch.zeros(Co, device='cuda'), torch.ones(Co, device='cuda')
+        bn = (engine._ptr(gamma), engine._ptr(beta), C.c_float(1e-3), ns.ACT_LEAKY, C.c_float(0.1), engine._ptr(y), engine._ptr(sm), engine._ptr(si),
+              engine._ptr(mm), engine._ptr(mv), C.c_float(0.99), None, _st())
+        if fused:
+            assert L.yk_conv3x3_bn_fwd_f32(engine._ptr(xd), engine._ptr(wd), *geom, Co, engine._ptr(zz), *bn) == 0, L.yk_last_error()
+        else:
+            zz.copy_(z)
+            assert L.yk_bn_train_fwd_res_f32(engine._ptr(zz), C.c_longlong(M), Co, *bn) == 0
+        outs.append([t.cpu().numpy() for t in (zz, y, sm, si, mm, mv)])
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    for u, v in zip(a[2:], b[2:]):
+        _close(v, u, 1e-6)
+    assert np.abs(a[1] - b[1]).max() <= 1e-5 * np.abs(a[1]).max()
+    # a 3-channel input is refused (the im2col path covers it)
+    assert L.yk_conv3x3_bn_fwd_f32(engine._ptr(xd), engine._ptr(wd), B, Hi, Wi, 3, Ho, Wo, stride, pt, pl, Co, engine._ptr(z), *nobn, _st()) != 0
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_depthwise_forward_and_both_gradients(stride):
     engine, L = _lib()
