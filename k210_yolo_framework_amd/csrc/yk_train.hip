@@ -11,6 +11,10 @@
 //   yk_dw3x3_{fwd,bwd_data,bwd_weight}_f32      DepthwiseConv2D
 //   yk_bn_train_fwd_f32 / yk_bn_train_bwd_f32   BatchNormalization in training mode fused with the activation
 //   yk_upsample2x_bwd_f32, yk_axpy_f32, yk_adam_f32 (Keras Adam incl. `decay`, keras_train.py:74-76)
+// Round 6 (what train.py calls now; the entry points above stay):
+//   yk_gemm_bn_fwd_f32 / yk_dw3x3_bn_fwd_f32     conv + BatchNorm forward in one call, the producer of z leaves the statistics' partial sums
+//   yk_gemm_f32_grouped / yk_dw3x3_bwd_weight_grouped_f32   all weight gradients of a backward pass in four launches
+//   yk_conv3x3_bn_fwd_f32 / _bwd_weight_f32 / _bwd_data_f32  3x3 convs as implicit GEMMs (no column matrix)
 #include "yk_common.h"
 #include <algorithm>
 #include <cmath>
